@@ -1,0 +1,75 @@
+"""Seeded synthetic MSRA-style depth frames (no dataset ships with the reference).
+
+The frame format is the payload of an MSRA ``.bin`` file as the reference reads it
+(``pre/read_MSRA.py:155-164``): a 6 x int32 header ``[W, H, left, top, right, bottom]``
+and ``(right-left)*(bottom-top)`` float32 depths in millimetres, row-major over the
+bounding box, 0 = background.  The generator follows SURVEY.md section 8(d): a
+hemispherical blob (the "hand") at 300-600 mm in front of a 320x240 camera, 1 mm
+Gaussian noise and 1 % dropped foreground pixels (holes).
+
+Two distributions:
+  * ``full``  - bbox = whole image (BASELINE.json configs[1], N = 76,800 px);
+  * ``crop``  - MSRA-like bounding boxes, side U(90,160) px, placed inside the image.
+
+Everything is numpy so the same frames can be produced here (goldens), in the tests
+and on the GPU box (bench) from the seed alone.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+IMG_W = 320
+IMG_H = 240
+
+
+def synth_frame(seed: int, kind: str = "full"):
+    """One frame -> (header int32[6], depth float32[b_w*b_h])."""
+    rng = np.random.default_rng(1234 + int(seed))
+    if kind == "full":
+        l, t, r, b = 0, 0, IMG_W, IMG_H
+    elif kind == "crop":
+        bw = int(rng.integers(90, 161))
+        bh = int(rng.integers(90, 161))
+        l = int(rng.integers(0, IMG_W - bw + 1))
+        t = int(rng.integers(0, IMG_H - bh + 1))
+        r, b = l + bw, t + bh
+    else:
+        raise ValueError("kind must be 'full' or 'crop'")
+    bw, bh = r - l, b - t
+    # Blob centre / radius in image pixels, kept inside the bbox.
+    rad_hi = min(90.0, 0.48 * min(bw, bh))
+    rad_lo = min(50.0, 0.6 * rad_hi)
+    rad = float(rng.uniform(rad_lo, rad_hi))
+    ecc = float(rng.uniform(0.75, 1.0))  # ellipse: shrink the y radius
+    cx = float(rng.uniform(l + rad, r - rad))
+    cy = float(rng.uniform(t + rad * ecc, b - rad * ecc))
+    base = float(rng.uniform(300.0, 600.0))
+    bulge = float(rng.uniform(20.0, 60.0))
+    xs = np.arange(l, r, dtype=np.float64)[None, :]
+    ys = np.arange(t, b, dtype=np.float64)[:, None]
+    rr = ((xs - cx) / rad) ** 2 + ((ys - cy) / (rad * ecc)) ** 2
+    inside = rr < 1.0
+    depth = base - bulge * np.sqrt(np.clip(1.0 - rr, 0.0, 1.0))
+    depth = depth + rng.normal(0.0, 1.0, size=depth.shape)
+    holes = rng.random(depth.shape) < 0.01
+    depth = np.where(inside & ~holes, depth, 0.0).astype(np.float32)
+    header = np.array([IMG_W, IMG_H, l, t, r, b], dtype=np.int32)
+    return header, np.ascontiguousarray(depth.reshape(-1))
+
+
+def synth_batch(n: int, kind: str = "full", seed0: int = 0):
+    """n frames packed back to back.
+
+    Returns (depth float32[sum N_i], offsets int64[n+1], headers int32[n,6]) - exactly
+    the three input arrays of ``tsdf_voxelize_hip`` (include/tsdf.h).
+    """
+    headers = np.empty((n, 6), dtype=np.int32)
+    chunks = []
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    for i in range(n):
+        h, d = synth_frame(seed0 + i, kind)
+        headers[i] = h
+        chunks.append(d)
+        offsets[i + 1] = offsets[i] + d.size
+    depth = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.float32)
+    return depth, offsets, headers

@@ -1,0 +1,250 @@
+/*
+ * tsdf_oracle.c — CPU restatement of the reference's projective-TSDF path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only
+ * as the checker / the reported CPU baseline.  Nothing under
+ * handposeestimation-with-3d-cnns_amd/ imports, links or calls it; the product
+ * path is the HIP library and has no CPU fallback.
+ *
+ * What it restates (all citations into /root/reference):
+ *   - AABB over all valid pixels      pre/tsdf_numba.py:84-96 (per pixel), :140-141 (final min/max)
+ *   - grid placement ("host glue")    pre/tsdf_numba.py:142-147  (== pre/tsdf_for.py:11-16)
+ *   - per-voxel TSDF                  pre/tsdf_numba.py:15-72    (== pre/tsdf_for.py:62-120 formula)
+ * with the arithmetic types numba infers for that file:
+ * float32 parameters, float64 intermediates (FOCAL is a Python float), unfused
+ * multiply-then-add for the pixel index, int() truncation toward zero, float32
+ * store.  Every division here is a true IEEE division.
+ *
+ * Parity pinning: tests/test_oracle_golden.py checks this file against golden
+ * vectors produced by running the reference's own pre/tsdf_for.py::tsdf_cal
+ * (the only runnable implementation) on float64-typed copies of the float32
+ * parameters — which makes the reference loop evaluate exactly the numba
+ * typing — and on the loop as it runs today (float32 scalars under numpy 2).
+ * The AABB half (min_max_kernel) has no runnable reference: it is pinned by
+ * restatement only ("numba path: restated, not executed").
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/tsdf.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* int() of a float64: truncate toward zero.  Out-of-range values saturate and NaN
+ * gives 0 (the gfx950 v_cvt_i32_f64 rule); both only arise for grids that touch the
+ * camera plane z = 0, which is outside the depth-camera domain. */
+static int32_t trunc_i32(double v) {
+  if (v != v) return 0;
+  if (v >= 2147483647.0) return INT32_MAX;
+  if (v <= -2147483648.0) return INT32_MIN;
+  return (int32_t)v;
+}
+
+static const tsdf_cam k_default_cam = {241.42, 160.0, 120.0, 1.0f, 3.0f};
+
+/*
+ * A.1 — pre/tsdf_numba.py:84-96 per pixel, :140-141 reduction.  Bounds-checked over
+ * exactly N = b_w*b_h pixels (the reference's out-of-bounds read at :83-86 and the
+ * "drop last block" hack at :138-139 are defects).
+ * Returns the number of valid pixels; min_p/max_p are untouched when it is 0.
+ */
+long tsdf_oracle_aabb(const float *depth, const int32_t *header, const tsdf_cam *cam,
+                      float *min_p, float *max_p) {
+  if (!cam) cam = &k_default_cam;
+  const int l = header[2], t = header[3], r = header[4], b = header[5];
+  const int bw = r - l, bh = b - t;
+  long n_valid = 0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int row = 0; row < bh; ++row) {
+    for (int col = 0; col < bw; ++col) {
+      const long pos = (long)row * bw + col;
+      const int x = col + l;          /* pos % b_w + l   :84 */
+      const int y = row + t;          /* pos // b_w + t  :85 (integer division, App. B#3) */
+      const float d = depth[pos];     /* :86 */
+      if (fabsf(d) < cam->invalid_eps) continue; /* :87 */
+      const double q = (double)d / cam->focal;                 /* :91 */
+      const float cxp = (float)(q * ((double)x - cam->cx));    /* :92, rounded by the f32 smem store :95 */
+      const float cyp = (float)(-q * ((double)y - cam->cy));   /* :93 */
+      const float czp = -d;                                    /* :94 */
+      if (cxp < mn[0]) mn[0] = cxp;
+      if (cyp < mn[1]) mn[1] = cyp;
+      if (czp < mn[2]) mn[2] = czp;
+      if (cxp > mx[0]) mx[0] = cxp;
+      if (cyp > mx[1]) mx[1] = cyp;
+      if (czp > mx[2]) mx[2] = czp;
+      ++n_valid;
+    }
+  }
+  if (n_valid) {
+    memcpy(min_p, mn, sizeof mn);
+    memcpy(max_p, mx, sizeof mx);
+  }
+  return n_valid;
+}
+
+/*
+ * A.2 — pre/tsdf_numba.py:142-147, all float32, evaluated left to right.
+ * grid[8] = mid_p[3], max_l, voxel_len, trunc_dis, 0, 0 ; ori[3] = vox_ori.
+ */
+void tsdf_oracle_glue(const float *min_p, const float *max_p, int R, const tsdf_cam *cam,
+                      float *grid, float *ori) {
+  if (!cam) cam = &k_default_cam;
+  float mid[3], len[3];
+  for (int a = 0; a < 3; ++a) {
+    mid[a] = (min_p[a] + max_p[a]) / 2.0f; /* :142 */
+    len[a] = max_p[a] - min_p[a];          /* :143 */
+  }
+  float max_l = len[0];                    /* :144 */
+  if (len[1] > max_l) max_l = len[1];
+  if (len[2] > max_l) max_l = len[2];
+  const float voxel_len = max_l / (float)R;              /* :145 */
+  const float trunc_dis = voxel_len * cam->trunc_voxels; /* :146 */
+  for (int a = 0; a < 3; ++a) {
+    float v = mid[a] - max_l / 2.0f;       /* :147 */
+    ori[a] = v + voxel_len / 2.0f;
+  }
+  grid[0] = mid[0]; grid[1] = mid[1]; grid[2] = mid[2];
+  grid[3] = max_l; grid[4] = voxel_len; grid[5] = trunc_dis;
+  grid[6] = 0.0f; grid[7] = 0.0f;
+}
+
+/*
+ * A.3 — pre/tsdf_numba.py:15-72 for every voxel of an R^3 grid.
+ * out: float32[3][R][R][R] in `layout`.  pixmap (optional, int32[R^3] indexed
+ * [z][y][x]): the gathered element index (pix_y-t)*b_w+pix_x-l, or -1 if the
+ * voxel projects outside the bbox (:36-37), or -2 - idx if the pixel there is
+ * invalid (:40-41).  It lets tests compare pixel maps exactly.
+ */
+void tsdf_oracle_voxels(const float *depth, const int32_t *header, const float *ori,
+                        float voxel_len, float trunc_dis, int R, const tsdf_cam *cam, int layout,
+                        float *out, int32_t *pixmap) {
+  if (!cam) cam = &k_default_cam;
+  const int l = header[2], t = header[3], r = header[4], b = header[5];
+  const int bw = r - l;
+  const size_t R3 = (size_t)R * R * R;
+  memset(out, 0, 3 * R3 * sizeof(float)); /* :33-35 */
+  const double F = cam->focal;
+  for (int z = 0; z < R; ++z) {
+    const double v_z = (double)ori[2] + (double)z * (double)voxel_len; /* :28 */
+    const double q = -F / v_z;                                         /* :30 */
+    for (int y = 0; y < R; ++y) {
+      const double v_y = (double)ori[1] + (double)y * (double)voxel_len; /* :27 */
+      const double py_f = (-v_y * q) + cam->cy;                          /* :32, mul then add */
+      const int32_t pix_y = trunc_i32(py_f);
+      for (int x = 0; x < R; ++x) {
+        const size_t vi = ((size_t)z * R + y) * R + x;
+        const double v_x = (double)ori[0] + (double)x * (double)voxel_len; /* :26 */
+        const double px_f = (v_x * q) + cam->cx;                           /* :31 */
+        const int32_t pix_x = trunc_i32(px_f);
+        if (pix_x < l || pix_x >= r || pix_y < t || pix_y >= b) {          /* :36 */
+          if (pixmap) pixmap[vi] = -1;
+          continue;
+        }
+        const int32_t idx = (pix_y - t) * bw + pix_x - l;                  /* :38 */
+        const float pd = depth[idx];                                       /* :39 */
+        if (fabsf(pd) < cam->invalid_eps) {                                /* :40 */
+          if (pixmap) pixmap[vi] = -2 - idx;
+          continue;
+        }
+        if (pixmap) pixmap[vi] = idx;
+        const double q2 = (double)pd / F;                                  /* :43 */
+        const double w_x = ((double)pix_x - cam->cx) * q2;                 /* :44 */
+        const double w_y = -((double)pix_y - cam->cy) * q2;                /* :45 */
+        const double w_z = -(double)pd;                                    /* :46 */
+        double ts[3];
+        ts[0] = fabs(v_x - w_x) / (double)trunc_dis;                       /* :47 */
+        ts[1] = fabs(v_y - w_y) / (double)trunc_dis;                       /* :48 */
+        ts[2] = fabs(v_z - w_z) / (double)trunc_dis;                       /* :49 */
+        const double dist = sqrt(ts[0] * ts[0] + ts[1] * ts[1] + ts[2] * ts[2]); /* :51-52 */
+        if (dist > 1.0) ts[0] = ts[1] = ts[2] = 1.0;                       /* :54-57 */
+        for (int a = 0; a < 3; ++a)
+          if (1.0 < ts[a]) ts[a] = 1.0;                                    /* :58-60 min(ts,1) */
+        if (w_z > v_z)                                                     /* :65 */
+          for (int a = 0; a < 3; ++a) ts[a] = -ts[a];
+        for (int a = 0; a < 3; ++a) {                                      /* :70-72 */
+          size_t o;
+          if (layout == TSDF_LAYOUT_CXYZ)
+            o = (size_t)a * R3 + ((size_t)x * R + y) * R + z;              /* pre/tsdf_for.py:118-120 */
+          else
+            o = (size_t)a * R3 + vi;
+          out[o] = (float)ts[a];
+        }
+      }
+    }
+  }
+}
+
+/* One frame end to end: cal_tsdf_cuda (pre/tsdf_numba.py:119-161) with the
+ * degenerate-frame convention of include/tsdf.h.  Returns the frame status. */
+static int oracle_frame(const float *depth, int64_t n_elem, const int32_t *header, int R,
+                        const tsdf_cam *cam, int layout, float *out, float *max_l, float *mid_p,
+                        float *aabb, float *grid_out, float *ori_out) {
+  const size_t R3 = (size_t)R * R * R;
+  const int bw = header[4] - header[2], bh = header[5] - header[3];
+  float grid[8] = {0}, ori[3] = {0}, mn[3] = {0}, mx[3] = {0};
+  int status = TSDF_FRAME_OK;
+  if (bw <= 0 || bh <= 0 || (int64_t)bw * bh != n_elem) {
+    status = TSDF_FRAME_BAD_HEADER;
+  } else {
+    long nv = tsdf_oracle_aabb(depth, header, cam, mn, mx);
+    if (nv == 0) {
+      status = TSDF_FRAME_DEGENERATE;
+    } else {
+      tsdf_oracle_glue(mn, mx, R, cam, grid, ori);
+      if (!(grid[3] > 0.0f) || !isfinite(grid[3])) {
+        status = TSDF_FRAME_DEGENERATE;
+        grid[3] = grid[4] = grid[5] = 0.0f;
+      }
+    }
+  }
+  if (status == TSDF_FRAME_OK) {
+    if (out) tsdf_oracle_voxels(depth, header, ori, grid[4], grid[5], R, cam, layout, out, NULL);
+  } else {
+    if (out) memset(out, 0, 3 * R3 * sizeof(float));
+  }
+  if (max_l) *max_l = grid[3];
+  if (mid_p) { mid_p[0] = grid[0]; mid_p[1] = grid[1]; mid_p[2] = grid[2]; }
+  if (aabb) { memcpy(aabb, mn, sizeof mn); memcpy(aabb + 3, mx, sizeof mx); }
+  if (grid_out) memcpy(grid_out, grid, sizeof grid);
+  if (ori_out) memcpy(ori_out, ori, sizeof ori);
+  return status;
+}
+
+/*
+ * Batch form with the same argument meaning as tsdf_voxelize_hip (include/tsdf.h),
+ * host pointers, OpenMP over frames.  n_threads <= 0 means 1.  Any output may be NULL.
+ * Returns the number of threads actually used.
+ */
+int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32_t *headers, int n,
+                         int R, const tsdf_cam *cam, int layout, int n_threads, float *out_tsdf,
+                         float *out_max_l, float *out_mid_p, int32_t *out_status, float *out_aabb,
+                         float *out_grid, float *out_ori) {
+  if (!cam) cam = &k_default_cam;
+  if (n_threads <= 0) n_threads = 1;
+  const size_t vol = (size_t)3 * R * R * R;
+  int used = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#endif
+  for (int i = 0; i < n; ++i) {
+#ifdef _OPENMP
+    if (i == 0) used = omp_get_num_threads();
+#endif
+    int st = oracle_frame(depth + offsets[i], offsets[i + 1] - offsets[i], headers + 6 * (size_t)i,
+                          R, cam, layout, out_tsdf ? out_tsdf + vol * i : NULL,
+                          out_max_l ? out_max_l + i : NULL, out_mid_p ? out_mid_p + 3 * (size_t)i : NULL,
+                          out_aabb ? out_aabb + 6 * (size_t)i : NULL,
+                          out_grid ? out_grid + 8 * (size_t)i : NULL,
+                          out_ori ? out_ori + 3 * (size_t)i : NULL);
+    if (out_status) out_status[i] = st;
+  }
+  return used;
+}
