@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the TSDF hot path: depth frames/s -> 32^3 TSDF (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one fused launch of the voxelizer over the rank's batch of 1024 synthetic
+320x240 full-frame depth crops (BASELINE.json configs[1]), inputs already resident in HBM.
+Frames are independent, so N GPUs = N ranks each voxelizing its own 1024-frame shard
+(weak scaling, no data-path collective; RCCL is used only for the start/stop barrier and
+the max-over-ranks of the elapsed time).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     the fused kernel against the HBM roofline: algorithmic bytes per launch
+               (24 + 4*N_px + 12*R^3 + 16 (+8 offsets) per frame) divided by
+               the mean launch duration measured with HIP events on the launch stream.
+  cpu_baseline the oracle (C restatement of the reference math, oracle/tsdf_oracle.c) timed on
+               this box's host cores on a bounded sample of the same frames (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_GPU = 1024
+RES = 32
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+
+
+def algorithmic_bytes(offsets: np.ndarray, n: int, R: int) -> int:
+    """header 24 + depth 4*N (read once) + tsdf 12*R^3 + max_l/mid_p 16 + offset 8."""
+    n_px = int(offsets[n] - offsets[0])
+    return 4 * n_px + n * (24 + 8 + 12 * R ** 3 + 16)
+
+
+def cpu_baseline(depth, offsets, headers, budget_s=12.0):
+    """Time the oracle on host cores: 1 thread and all cores, on a bounded prefix of the batch."""
+    import oracle  # test infrastructure; used here only as the reported CPU baseline
+
+    cores = os.cpu_count() or 1
+    oracle.lib()  # build/load outside the timed region
+
+    def timed(n, threads):
+        t0 = time.perf_counter()
+        r = oracle.voxelize(depth[: offsets[n]], offsets[: n + 1], headers[:n], R=RES, n_threads=threads)
+        return time.perf_counter() - t0, r["threads"]
+
+    t1, _ = timed(16, 1)                       # probe: 16 frames on one thread
+    per_frame_1t = t1 / 16
+    n1 = int(max(16, min(FRAMES_PER_GPU, (budget_s / 3) / per_frame_1t)))
+    t1, _ = timed(n1, 1)
+    fps_1t = n1 / t1
+    nall = int(max(cores, min(FRAMES_PER_GPU, (budget_s * 2 / 3) * fps_1t * cores * 0.7)))
+    tall, used = timed(nall, cores)
+    return {
+        "value": round(nall / tall, 2), "unit": "frames/s", "cores": int(used), "kind": "port",
+        "sample": f"oracle/tsdf_oracle.c (C restatement of pre/tsdf_numba.py math; the numba path itself is "
+                  f"not runnable) on the first {nall} of the same frames, {used} OpenMP threads, {tall:.2f} s; "
+                  f"single thread: {fps_1t:.1f} frames/s on {n1} frames",
+        "single_thread_value": round(fps_1t, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the voxelizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL: barrier + max of elapsed only
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
+    synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+
+    # this rank's shard: frames [rank*1024, (rank+1)*1024) of the seeded synthetic set
+    depth, offsets, headers = synth.synth_batch(FRAMES_PER_GPU, "full", seed0=rank * FRAMES_PER_GPU)
+    td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, offsets, headers))
+    out = pkg.voxelize(td, to, th, res=RES)  # allocates the outputs once
+    torch.cuda.synchronize()
+    assert bool((out.status == 0).all())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pkg.voxelize(td, to, th, res=RES, out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()                      # on torch's current stream == the launch stream
+        pkg.voxelize(td, to, th, res=RES, out=out)
+        ev[k][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kern_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    abytes = algorithmic_bytes(offsets, FRAMES_PER_GPU, RES)
+
+    if rank == 0:
+        total_frames = world * FRAMES_PER_GPU * args.steps
+        mean_ms = float(kern_ms.mean())
+        achieved = abytes / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "depth frames/sec to 32^3 TSDF",
+            "value": round(total_frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: batch 1024 synthetic 320x240 full-frame depth crops -> 32^3 "
+                            "3-channel TSDF per GPU, inputs resident in HBM, one fused launch per step",
+                "frames_per_gpu": FRAMES_PER_GPU, "res": RES, "layout": "czyx",
+                "parallelism": f"frame-sharded x{world}, no collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "tsdf_fused_kernel<32,0>", "algorithmic_bytes_per_launch": abytes,
+                "launch_ms_mean": round(mean_ms, 4), "launch_ms_median": round(float(np.median(kern_ms)), 4),
+                "launch_ms_min": round(float(kern_ms.min()), 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(depth, offsets, headers)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
