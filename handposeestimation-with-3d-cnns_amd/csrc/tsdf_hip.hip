@@ -9,19 +9,26 @@
 // unfused multiply-then-add for the pixel index, float32 store).
 //
 // Design (DESIGN.md has the numbers):
-//   * one 256-thread workgroup (4 wave64) per frame; the AABB never leaves the chip;
+//   * one 1024-thread workgroup (16 wave64) per frame, one workgroup per CU (it owns the LDS);
+//     the AABB and the grid placement never leave the chip;
 //   * phase 1 streams the crop once with 16-byte loads, lane <-> 4 consecutive columns,
 //     wave <-> rows.  It does NOT back-project every pixel (one float64 division each):
 //     f32(f64(d)/F * (x-cx)) is monotone in d for a fixed column x (and likewise per row),
 //     so the AABB is the extreme of the formula applied to each column's / row's (min,max)
-//     valid depth — 2(b_w+b_h) divisions per wave instead of b_w*b_h, bit-identical result;
+//     valid depth — 2(b_w+b_h) divisions per wave instead of b_w*b_h, bit-identical result.
+//     The same pass yields the pixel rectangle that holds every valid pixel;
+//   * staging: that rectangle (the only pixels phase 2 can ever use — everything outside it is
+//     rejected by pre/tsdf_numba.py:36 or :40) is copied into LDS (up to 144 KiB), so the
+//     per-voxel gather is an LDS read: no vector-memory latency, and stores never block loads;
+//     a rectangle that does not fit falls back to gathering from global memory (L2);
 //   * phase 2: each lane owns 4 consecutive voxels along the layout's fastest axis, so every
 //     wave store is 1 KiB contiguous (global_store_dwordx4); q = -F/v_z comes from a 1-per-z
-//     LDS table (true division), the per-voxel chain uses reciprocals (<= 2 ulp64 from the
-//     divisions it replaces — 9 orders of magnitude inside the 1e-5 parity bound);
-//   * memory-bound streaming read + streaming write; the gather re-reads lines the same
-//     workgroup has just streamed (L2 / Infinity Cache), counted once in the roofline.
-// No MFMA (gather/scatter, not a contraction), no CPU fallback, gfx950 only.
+//     LDS table (true division), the per-voxel chain uses reciprocals (<= a few ulp64 from the
+//     divisions it replaces — 9 orders of magnitude inside the 1e-5 parity bound); a wave whose
+//     256 voxels are all rejected or farther than the truncation distance along z skips the
+//     x/y terms (the result is then (+-1,+-1,+-1) or 0 by pre/tsdf_numba.py:54-57).
+// HBM-bound streaming read + streaming write.  No MFMA (gather/scatter, not a contraction),
+// no CPU fallback, gfx950 only.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,10 +37,12 @@
 
 namespace {
 
-constexpr int kWG = 256;            // threads per workgroup
-constexpr int kWaves = kWG / 64;    // wave64
-constexpr int kRowUnroll = 4;       // rows in flight per wave in phase 1
+constexpr int kWG = 1024;               // threads per workgroup
+constexpr int kWaves = kWG / 64;        // wave64
+constexpr int kRowUnroll = 4;           // rows in flight per wave in phase 1
 constexpr int kMaxR = 128;
+constexpr int kStageFloats = 36 * 1024; // 144 KiB depth stage in LDS
+constexpr int kRedStride = 12;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-B access
@@ -45,32 +54,71 @@ struct CamK {
 
 #define TSDF_INF __builtin_inff()
 
-// ---- wave64 reductions on DPP (result valid in every lane after the readlane) -------------
-template <int Ctrl>
-__device__ __forceinline__ float dpp_get(float v) {
-  // lanes whose DPP source is out of range keep their own value ("old" = v)
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), Ctrl, 0xf,
-                                                    0xf, false));
+// ---- raw VALU min/max (no canonicalising v_max x,x,x in front; operands here are never NaN) ----
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max(|a|,|b|,|c|,|d|); NaN operands are ignored (IEEE maxNum), all-NaN gives NaN.
+__device__ __forceinline__ float vmaxabs4(f4 v) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, %0, |%4|"
+      : "=&v"(r)
+      : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+  return r;
 }
 
-__device__ __forceinline__ float wave_min(float v) {
-  v = fminf(v, dpp_get<0x111>(v));  // row_shr:1
-  v = fminf(v, dpp_get<0x112>(v));  // row_shr:2
-  v = fminf(v, dpp_get<0x114>(v));  // row_shr:4
-  v = fminf(v, dpp_get<0x118>(v));  // row_shr:8   -> lane 15 of each row holds the row's min
-  v = fminf(v, dpp_get<0x142>(v));  // row_bcast:15
-  v = fminf(v, dpp_get<0x143>(v));  // row_bcast:31 -> lane 63 holds the wave's min
+// ---- wave64 reductions: one DPP VALU op per step (s_nop 1 covers the VALU-write -> DPP-read hazard;
+// lanes whose DPP source is out of range are write-disabled and keep their value) ----------------
+#define TSDF_DPP_REDUCE(OP)                                                             \
+  asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"        \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"        \
+      "s_nop 1"                                                                         \
+      : "+v"(v))
+#define TSDF_DPP_REDUCE16(OP)                                                           \
+  asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"           \
+      "s_nop 1"                                                                         \
+      : "+v"(v))
+
+__device__ __forceinline__ float wave_min(float v) {  // result in every lane (wave-uniform)
+  TSDF_DPP_REDUCE("v_min_f32_dpp");
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, dpp_get<0x111>(v));
-  v = fmaxf(v, dpp_get<0x112>(v));
-  v = fmaxf(v, dpp_get<0x114>(v));
-  v = fmaxf(v, dpp_get<0x118>(v));
-  v = fmaxf(v, dpp_get<0x142>(v));
-  v = fmaxf(v, dpp_get<0x143>(v));
+  TSDF_DPP_REDUCE("v_max_f32_dpp");
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// reduce lanes 0..15 only (first DPP row); result wave-uniform
+__device__ __forceinline__ float row0_min(float v) {
+  TSDF_DPP_REDUCE16("v_min_f32_dpp");
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+}
+__device__ __forceinline__ float row0_max(float v) {
+  TSDF_DPP_REDUCE16("v_max_f32_dpp");
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
 }
 
 // ---- exact float64 helpers (never contracted) ----------------------------------------------
@@ -114,23 +162,20 @@ __device__ __forceinline__ f4 load_row4(const float *__restrict__ rp, int c, int
   return v;
 }
 
-__device__ __forceinline__ void acc1(float d, float eps, float &cmin, float &cmax, float &rmin,
-                                     float &rmax) {
-  const bool ok = __builtin_fabsf(d) >= eps;  // NaN -> invalid
-  const float lo = ok ? d : TSDF_INF;
-  const float hi = ok ? d : -TSDF_INF;
-  cmin = fminf(cmin, lo);
-  cmax = fmaxf(cmax, hi);
-  rmin = fminf(rmin, lo);
-  rmax = fmaxf(rmax, hi);
-}
-
 __device__ __forceinline__ void acc4(f4 v, float eps, float (&cmin)[4], float (&cmax)[4], float &rmin,
                                      float &rmax) {
-  acc1(v.x, eps, cmin[0], cmax[0], rmin, rmax);
-  acc1(v.y, eps, cmin[1], cmax[1], rmin, rmax);
-  acc1(v.z, eps, cmin[2], cmax[2], rmin, rmax);
-  acc1(v.w, eps, cmin[3], cmax[3], rmin, rmax);
+  float lo[4], hi[4];
+  const float d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = __builtin_fabsf(d[j]) >= eps;  // pre/tsdf_numba.py:87 (NaN -> invalid)
+    lo[j] = ok ? d[j] : TSDF_INF;
+    hi[j] = ok ? d[j] : -TSDF_INF;
+    cmin[j] = vmin(cmin[j], lo[j]);
+    cmax[j] = vmax(cmax[j], hi[j]);
+  }
+  rmin = vmin3(vmin3(rmin, lo[0], lo[1]), lo[2], lo[3]);
+  rmax = vmax3(vmax3(rmax, hi[0], hi[1]), hi[2], hi[3]);
 }
 
 struct Frame {
@@ -144,13 +189,18 @@ struct Grid {
   float ori[3];
 };
 
+struct Aabb {
+  float mn[3], mx[3];
+  int c0, c1, r0, r1;  // bbox-relative rectangle holding every valid pixel (inclusive)
+  bool any;
+};
+
 // ---- phase 1: AABB of all valid back-projected pixels ---------------------------------------
-// Returns (in every thread) min/max xyz; `any` is false when the frame has no valid pixel.
-__device__ __forceinline__ void phase1_aabb(const Frame &f, const CamK &k, float (&red)[kWaves][8],
-                                            float (&mn)[3], float (&mx)[3], bool &any) {
+__device__ __forceinline__ Aabb phase1_aabb(const Frame &f, const CamK &k, float *red) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float xmn = TSDF_INF, xmx = -TSDF_INF, ymn = TSDF_INF, ymx = -TSDF_INF;
   float dmn = TSDF_INF, dmx = -TSDF_INF;
+  float cimn = TSDF_INF, cimx = -TSDF_INF, rimn = TSDF_INF, rimx = -TSDF_INF;  // indices (exact in f32)
   // per-wave stash of reduced row extremes: lane i keeps the i-th non-empty row piece
   float s_rmin = TSDF_INF, s_rmax = -TSDF_INF;
   int s_row = 0, cnt = 0;
@@ -159,8 +209,10 @@ __device__ __forceinline__ void phase1_aabb(const Frame &f, const CamK &k, float
     if (s_rmin <= s_rmax) {
       const int y = f.t + s_row;
       const float a = backproject_y(s_rmin, y, k), b = backproject_y(s_rmax, y, k);
-      ymn = fminf(ymn, fminf(a, b));
-      ymx = fmaxf(ymx, fmaxf(a, b));
+      ymn = vmin3(ymn, a, b);
+      ymx = vmax3(ymx, a, b);
+      rimn = vmin(rimn, (float)s_row);
+      rimx = vmax(rimx, (float)s_row);
     }
     s_rmin = TSDF_INF;
     s_rmax = -TSDF_INF;
@@ -198,9 +250,10 @@ __device__ __forceinline__ void phase1_aabb(const Frame &f, const CamK &k, float
       for (int u = 0; u < kRowUnroll; ++u) {
         const int row = row0 + kWaves * u;
         float rmin = TSDF_INF, rmax = -TSDF_INF;
-        acc4(va[u], k.eps, cmin[0], cmax[0], rmin, rmax);
-        if (has1) acc4(vb[u], k.eps, cmin[1], cmax[1], rmin, rmax);
-        if (__any(rmin <= rmax)) {  // skip the reduction for rows without a valid pixel
+        // most 256-pixel segments hold no valid pixel at all: skip them wave-wide
+        if (__any(vmaxabs4(va[u]) >= k.eps)) acc4(va[u], k.eps, cmin[0], cmax[0], rmin, rmax);
+        if (has1 && __any(vmaxabs4(vb[u]) >= k.eps)) acc4(vb[u], k.eps, cmin[1], cmax[1], rmin, rmax);
+        if (__any(rmin <= rmax)) {
           const float wmin = wave_min(rmin), wmax = wave_max(rmax);
           if (lane == cnt) {
             s_rmin = wmin;
@@ -211,56 +264,65 @@ __device__ __forceinline__ void phase1_aabb(const Frame &f, const CamK &k, float
         }
       }
     }
-    // column extremes of this wave's rows -> x extent, depth extremes -> z extent
+    // column extremes of this wave's rows -> x extent; depth extremes -> z extent
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (cmin[kk][j] <= cmax[kk][j]) {
-          const int x = f.l + c0 + 256 * kk + j;
+          const int col = c0 + 256 * kk + j;
+          const int x = f.l + col;
           const float a = backproject_x(cmin[kk][j], x, k), b = backproject_x(cmax[kk][j], x, k);
-          xmn = fminf(xmn, fminf(a, b));
-          xmx = fmaxf(xmx, fmaxf(a, b));
-          dmn = fminf(dmn, cmin[kk][j]);
-          dmx = fmaxf(dmx, cmax[kk][j]);
+          xmn = vmin3(xmn, a, b);
+          xmx = vmax3(xmx, a, b);
+          dmn = vmin(dmn, cmin[kk][j]);
+          dmx = vmax(dmx, cmax[kk][j]);
+          cimn = vmin(cimn, (float)col);
+          cimx = vmax(cimx, (float)col);
         }
       }
   }
   flush_rows();
 
-  xmn = wave_min(xmn);
-  ymn = wave_min(ymn);
-  dmn = wave_min(dmn);
-  xmx = wave_max(xmx);
-  ymx = wave_max(ymx);
-  dmx = wave_max(dmx);
-  if (lane == 0) {
-    red[wave][0] = xmn;
-    red[wave][1] = ymn;
-    red[wave][2] = dmn;
-    red[wave][3] = xmx;
-    red[wave][4] = ymx;
-    red[wave][5] = dmx;
+  // wave -> LDS -> every wave reduces the 16 partials itself (no second barrier)
+  float part[10];
+  part[0] = wave_min(xmn);
+  part[1] = wave_min(ymn);
+  part[2] = wave_min(dmn);
+  part[3] = wave_min(cimn);
+  part[4] = wave_min(rimn);
+  part[5] = wave_max(xmx);
+  part[6] = wave_max(ymx);
+  part[7] = wave_max(dmx);
+  part[8] = wave_max(cimx);
+  part[9] = wave_max(rimx);
+  if (lane < 10) {
+    float v = part[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) v = (lane == i) ? part[i] : v;
+    red[wave * kRedStride + lane] = v;
   }
   __syncthreads();
-  xmn = ymn = dmn = TSDF_INF;
-  xmx = ymx = dmx = -TSDF_INF;
+  float fin[10];
+  const int src = (lane & 15) * kRedStride;
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    xmn = fminf(xmn, red[w][0]);
-    ymn = fminf(ymn, red[w][1]);
-    dmn = fminf(dmn, red[w][2]);
-    xmx = fmaxf(xmx, red[w][3]);
-    ymx = fmaxf(ymx, red[w][4]);
-    dmx = fmaxf(dmx, red[w][5]);
-  }
-  any = dmn <= dmx;
-  mn[0] = xmn;
-  mn[1] = ymn;
-  mn[2] = -dmx;  // cam_z = -d   pre/tsdf_numba.py:94
-  mx[0] = xmx;
-  mx[1] = ymx;
-  mx[2] = -dmn;
+  for (int i = 0; i < 5; ++i) fin[i] = row0_min(red[src + i]);
+#pragma unroll
+  for (int i = 5; i < 10; ++i) fin[i] = row0_max(red[src + i]);
+
+  Aabb a;
+  a.any = fin[2] <= fin[7];
+  a.mn[0] = fin[0];
+  a.mn[1] = fin[1];
+  a.mn[2] = -fin[7];  // cam_z = -d   pre/tsdf_numba.py:94
+  a.mx[0] = fin[5];
+  a.mx[1] = fin[6];
+  a.mx[2] = -fin[2];
+  a.c0 = a.any ? (int)fin[3] : 0;
+  a.c1 = a.any ? (int)fin[8] : -1;
+  a.r0 = a.any ? (int)fin[4] : 0;
+  a.r1 = a.any ? (int)fin[9] : -1;
+  return a;
 }
 
 // ---- glue: pre/tsdf_numba.py:142-147, float32, left to right --------------------------------
@@ -281,35 +343,17 @@ __device__ __forceinline__ Grid glue(const float (&mn)[3], const float (&mx)[3],
   return g;
 }
 
-// ---- phase 2 per-voxel value: pre/tsdf_numba.py:43-68 ---------------------------------------
+// ---- phase 2 ---------------------------------------------------------------------------------
 struct VoxK {
-  double cx, cy, inv_focal, inv_trunc;
+  double cx, cy;
+  double it;   // 1 / trunc_dis
+  double kq;   // (1/F) * it
+  double ncx;  // -cx
   float eps;
+  int px0, px1, py0, py1;  // image-coordinate rectangle (inclusive) holding every valid pixel
+  int stride;              // gather source: elements per row ...
+  int base;                // ... and index of pixel (px0, py0)
 };
-
-__device__ __forceinline__ void tsdf_value(double vx, double vy, double vz, int pix_x, int pix_y, float pd,
-                                           bool inb, const VoxK &k, float &ox, float &oy, float &oz) {
-  const bool ok = inb && (__builtin_fabsf(pd) >= k.eps);         // :36,:40
-  const double pd64 = (double)pd;
-  const double q2 = pd64 * k.inv_focal;                           // :43 (reciprocal form)
-  const double wx = ((double)pix_x - k.cx) * q2;                  // :44
-  const double wy = -((double)pix_y - k.cy) * q2;                 // :45
-  const double tx = __builtin_fabs(vx - wx) * k.inv_trunc;        // :47
-  const double ty = __builtin_fabs(vy - wy) * k.inv_trunc;        // :48
-  const double tz = __builtin_fabs(vz + pd64) * k.inv_trunc;      // :49, w_z = -pd :46
-  const double s = __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx));  // dist^2 :51-52
-  const bool far = s > 1.0;                                       // :54  (sqrt is monotone, sqrt(1)=1)
-  float fx = (far || tx > 1.0) ? 1.0f : (float)tx;                // :55-60, f32 store :70-72
-  float fy = (far || ty > 1.0) ? 1.0f : (float)ty;
-  float fz = (far || tz > 1.0) ? 1.0f : (float)tz;
-  const bool neg = (-pd64) > vz;                                  // :65
-  fx = neg ? -fx : fx;
-  fy = neg ? -fy : fy;
-  fz = neg ? -fz : fz;
-  ox = ok ? fx : 0.0f;                                            // :33-41
-  oy = ok ? fy : 0.0f;
-  oz = ok ? fz : 0.0f;
-}
 
 __device__ __forceinline__ void zero_volume(float *__restrict__ out, int R) {
   const int n4 = 3 * R * R * R / 4;
@@ -318,7 +362,150 @@ __device__ __forceinline__ void zero_volume(float *__restrict__ out, int R) {
   for (int i = threadIdx.x; i < n4; i += kWG) o4[i] = z;
 }
 
-// LAYOUT 0: o[c][z][y][x], lanes run along x.   LAYOUT 1: o[c][x][y][z], lanes run along z.
+// One group of 4 voxels along the fast axis (pre/tsdf_numba.py:26-72 for each).
+// LAYOUT 0: the 4 voxels differ in x (same y, z) and use vx[0..3], vz[0], q[0], negthr[0];
+// LAYOUT 1: they differ in z (same x, y)    and use vx[0], vz[0..3], q[0..3], negthr[0..3].
+// Coordinates are pre-scaled by it = 1/trunc_dis:
+//   tx = (v_x - w_x)/trunc = v_x*it - (pix_x-cx)*(pd*kq),  tz = v_z*it + pd*it  (w_z = -pd).
+template <int LAYOUT>
+__device__ __forceinline__ void voxel_group4(const double (&vx)[4], const double vy, const double (&vz)[4],
+                                             const double (&q)[4], const float (&negthr)[4], const VoxK &k,
+                                             const float *__restrict__ src, f4 &o0, f4 &o1, f4 &o2) {
+  int pix_x[4], pix_y[4];
+  bool inb[4];
+  float pd[4];
+  const double nvy = -vy;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jx = LAYOUT == 0 ? j : 0, jz = LAYOUT == 0 ? 0 : j;
+    if (LAYOUT == 0 && j > 0) {
+      pix_y[j] = pix_y[0];
+    } else {
+      pix_y[j] = trunc_i32(mul_then_add(nvy, q[jz], k.cy));                 // :32
+    }
+    pix_x[j] = trunc_i32(mul_then_add(vx[jx], q[jz], k.cx));                // :31
+    // :36 restricted to the rectangle that holds every valid pixel (outside it :36 or :40 rejects)
+    inb[j] = (unsigned)(pix_x[j] - k.px0) <= (unsigned)(k.px1 - k.px0) &&
+             (unsigned)(pix_y[j] - k.py0) <= (unsigned)(k.py1 - k.py0);
+    const int idx = inb[j] ? (pix_y[j] - k.py0) * k.stride + (pix_x[j] - k.px0) + k.base : k.base;
+    pd[j] = src[idx];                                                       // :38-39
+  }
+  bool ok[4], neg[4];
+  double pd64[4], tz[4];
+  bool any_near = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jz = LAYOUT == 0 ? 0 : j;
+    ok[j] = inb[j] && (__builtin_fabsf(pd[j]) >= k.eps);                    // :40
+    pd64[j] = (double)pd[j];
+    tz[j] = __builtin_fma(pd64[j], k.it, vz[jz] * k.it);                    // :46,:49
+    neg[j] = pd[j] < negthr[jz];                                            // w_z > v_z  :65
+    any_near |= ok[j] && (__builtin_fabs(tz[j]) <= 1.0);
+  }
+  float r0[4], r1[4], r2[4];
+  if (__any(any_near)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jx = LAYOUT == 0 ? j : 0;
+      const double a = pd64[j] * k.kq;                                      // pd/F/trunc      :43
+      const double wx = ((double)pix_x[j] + k.ncx) * a;                     // w_x/trunc       :44
+      const double wy = (k.cy - (double)pix_y[j]) * a;                      // w_y/trunc       :45
+      const double tx = __builtin_fma(vx[jx], k.it, -wx);                   // (v_x-w_x)/trunc :47
+      const double ty = __builtin_fma(vy, k.it, -wy);                       // :48
+      const double s = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));  // dist^2 :51-52
+      const bool far = !(s <= 1.0);                                         // :54 (sqrt monotone, sqrt(1)=1)
+      r0[j] = far ? 1.0f : fminf(__builtin_fabsf((float)tx), 1.0f);         // :55-60, f32 store :70-72
+      r1[j] = far ? 1.0f : fminf(__builtin_fabsf((float)ty), 1.0f);
+      r2[j] = far ? 1.0f : fminf(__builtin_fabsf((float)tz[j]), 1.0f);
+    }
+  } else {
+    // every voxel of this wave is rejected or beyond the truncation distance along z alone:
+    // dist >= |tz| > 1  ->  (1,1,1)   pre/tsdf_numba.py:54-57
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r0[j] = r1[j] = r2[j] = 1.0f;
+  }
+  float *p0 = reinterpret_cast<float *>(&o0), *p1 = reinterpret_cast<float *>(&o1),
+        *p2 = reinterpret_cast<float *>(&o2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sg = neg[j] ? -1.0f : 1.0f;
+    p0[j] = ok[j] ? sg * r0[j] : 0.0f;                                      // :33-41, :65-68
+    p1[j] = ok[j] ? sg * r1[j] : 0.0f;
+    p2[j] = ok[j] ? sg * r2[j] : 0.0f;
+  }
+}
+
+// smallest float32 >= t  (so that for a float32 p:  p < t  <=>  p < result)
+__device__ __forceinline__ float f32_round_up(double t) {
+  float f = (float)t;
+  if ((double)f < t) f = nextafterf(f, TSDF_INF);
+  return f;
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void phase2(const Grid &g, const VoxK &vk, int R, const double *qtab,
+                                       const float *negtab, const float *__restrict__ src,
+                                       float *__restrict__ out) {
+  const int tid = threadIdx.x;
+  const double vl = (double)g.voxel_len;
+  const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
+  const int R4 = R / 4;
+  const int G = R * R4;  // groups of 4 voxels per slow-axis slice
+  const int64_t R3 = (int64_t)R * R * R;
+
+  // slow axis s (z for LAYOUT 0, x for LAYOUT 1); group gi -> (y, fast4)
+  int g0, gstep, s0, sstep;
+  if (G <= kWG && (kWG % G) == 0) {
+    g0 = tid % G;
+    gstep = G;  // one group per thread, kWG/G slices at a time
+    s0 = tid / G;
+    sstep = kWG / G;
+  } else {
+    g0 = tid;
+    gstep = kWG;
+    s0 = 0;
+    sstep = 1;
+  }
+  for (int gi = g0; gi < G; gi += gstep) {
+    const int f4i = (gi % R4) * 4;
+    const int y = gi / R4;
+    const double vy = oy + (double)y * vl;                                  // :27
+    double vx[4], vz[4], q[4];
+    float negthr[4];
+    if constexpr (LAYOUT == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vx[j] = ox + (double)(f4i + j) * vl;      // :26
+      for (int z = s0; z < R; z += sstep) {
+        vz[0] = oz + (double)z * vl;                                        // :28
+        q[0] = qtab[z];
+        negthr[0] = negtab[z];
+        f4 o0, o1, o2;
+        voxel_group4<0>(vx, vy, vz, q, negthr, vk, src, o0, o1, o2);
+        const int64_t e = ((int64_t)z * R + y) * R + f4i;                   // o[c][z][y][x] :70-72
+        *reinterpret_cast<f4 *>(out + e) = o0;
+        *reinterpret_cast<f4 *>(out + R3 + e) = o1;
+        *reinterpret_cast<f4 *>(out + 2 * R3 + e) = o2;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vz[j] = oz + (double)(f4i + j) * vl;
+        q[j] = qtab[f4i + j];
+        negthr[j] = negtab[f4i + j];
+      }
+      for (int x = s0; x < R; x += sstep) {
+        vx[0] = ox + (double)x * vl;
+        f4 o0, o1, o2;
+        voxel_group4<1>(vx, vy, vz, q, negthr, vk, src, o0, o1, o2);
+        const int64_t e = ((int64_t)x * R + y) * R + f4i;                   // o[c][x][y][z] tsdf_for.py:118-120
+        *reinterpret_cast<f4 *>(out + e) = o0;
+        *reinterpret_cast<f4 *>(out + R3 + e) = o1;
+        *reinterpret_cast<f4 *>(out + 2 * R3 + e) = o2;
+      }
+    }
+  }
+}
+
 template <int RT, int LAYOUT>
 __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     const float *__restrict__ depth, const int64_t *__restrict__ offsets,
@@ -326,13 +513,15 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
     float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
     int aabb_only) {
-  __shared__ float red[kWaves][8];
+  __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
   __shared__ double qtab[kMaxR];
+  __shared__ float negtab[kMaxR];
+  __shared__ float red[kWaves * kRedStride];
 
   const int R = RT ? RT : Rrt;
   const int frame = blockIdx.x;
   if (frame >= n) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   const int32_t *h = headers + 6 * (int64_t)frame;
   Frame f;
@@ -347,7 +536,11 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
   float *out = out_tsdf ? out_tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
 
   int status = TSDF_FRAME_OK;
-  float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+  Aabb ab;
+  ab.any = false;
+  ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+  ab.c0 = ab.r0 = 0;
+  ab.c1 = ab.r1 = -1;
   Grid g;
   g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
   g.max_l = g.voxel_len = g.trunc = 0.f;
@@ -356,13 +549,12 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
   if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != off1 - off0) {
     status = TSDF_FRAME_BAD_HEADER;  // block-uniform
   } else {
-    bool any;
-    phase1_aabb(f, cam, red, mn, mx, any);
-    if (!any) {
+    ab = phase1_aabb(f, cam, red);
+    if (!ab.any) {
       status = TSDF_FRAME_DEGENERATE;
-      mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0.f;
+      ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
     } else {
-      g = glue(mn, mx, R, cam);
+      g = glue(ab.mn, ab.mx, R, cam);
       if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF)) {
         status = TSDF_FRAME_DEGENERATE;
         g.max_l = g.voxel_len = g.trunc = 0.f;
@@ -380,8 +572,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     if (out_status) out_status[frame] = status;
     if (out_aabb) {
       float *a = out_aabb + 6 * (int64_t)frame;
-      a[0] = mn[0]; a[1] = mn[1]; a[2] = mn[2];
-      a[3] = mx[0]; a[4] = mx[1]; a[5] = mx[2];
+      a[0] = ab.mn[0]; a[1] = ab.mn[1]; a[2] = ab.mn[2];
+      a[3] = ab.mx[0]; a[4] = ab.mx[1]; a[5] = ab.mx[2];
     }
     if (out_grid) {
       float *q = out_grid + 8 * (int64_t)frame;
@@ -399,98 +591,60 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     return;
   }
 
-  // ---- phase 2 ----
+  // ---- per-z tables (true divisions, once per z) ----
   const double vl = (double)g.voxel_len;
-  const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
   if (tid < R) {
-    const double v_z = oz + (double)tid * vl;  // :28
-    qtab[tid] = -cam.focal / v_z;              // :30, true division, once per z
+    const double v_z = (double)g.ori[2] + (double)tid * vl;  // :28
+    qtab[tid] = -cam.focal / v_z;                            // :30
+    negtab[tid] = f32_round_up(-v_z);                        // pd < -v_z  <=>  w_z > v_z  (:65)
+  }
+
+  // ---- stage the rectangle of valid pixels into LDS ----
+  const int sw = ab.c1 - ab.c0 + 1, sh = ab.r1 - ab.r0 + 1;
+  const bool staged = (int64_t)sw * sh <= kStageFloats;  // block-uniform
+  if (staged) {
+    const float *__restrict__ srcp = f.depth + (int64_t)ab.r0 * f.bw + ab.c0;
+    for (int r0 = wave; r0 < sh; r0 += kWaves * 4) {
+      for (int cb = 0; cb < sw; cb += 256) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
+            v[u][kk] = (r < sh && c < sw) ? srcp[(int64_t)r * f.bw + c] : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
+            if (r < sh && c < sw) stage[r * sw + c] = v[u][kk];
+          }
+      }
+    }
   }
   __syncthreads();
 
   VoxK vk;
   vk.cx = cam.cx;
   vk.cy = cam.cy;
-  vk.inv_focal = cam.inv_focal;
-  vk.inv_trunc = 1.0 / (double)g.trunc;
+  vk.it = 1.0 / (double)g.trunc;
+  vk.kq = cam.inv_focal * vk.it;
+  vk.ncx = -cam.cx;
   vk.eps = cam.eps;
-
-  const int R4 = R / 4;
-  const int groups = R * R4;          // (y, fast/4) pairs per slow-axis slice
-  const int64_t R3 = (int64_t)R * R * R;
-  const float *__restrict__ fd = f.depth;
-
-  for (int gi = tid; gi < groups; gi += kWG) {
-    const int f4i = (gi % R4) * 4;    // first of 4 consecutive indices on the fast axis
-    const int y = gi / R4;
-    const double vy = oy + (double)y * vl;  // :27
-    const double nvy = -vy;
-
-    if constexpr (LAYOUT == 0) {
-      // fast axis = x.  v_x fixed per lane; loop over z.
-      double vx[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vx[j] = ox + (double)(f4i + j) * vl;  // :26
-      for (int z = 0; z < R; ++z) {
-        const double vz = oz + (double)z * vl;
-        const double q = qtab[z];
-        const int pix_y = trunc_i32(mul_then_add(nvy, q, cam.cy));      // :32
-        const bool row_ok = pix_y >= f.t && pix_y < f.b;
-        const int rowoff = (pix_y - f.t) * f.bw - f.l;
-        int pix_x[4];
-        bool inb[4];
-        float pd[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pix_x[j] = trunc_i32(mul_then_add(vx[j], q, cam.cx));         // :31
-          inb[j] = row_ok && pix_x[j] >= f.l && pix_x[j] < f.r;         // :36
-          pd[j] = fd[inb[j] ? rowoff + pix_x[j] : 0];                   // :38-39
-        }
-        f4 o0, o1, o2;
-        { float a_, b_, c_; tsdf_value(vx[0], vy, vz, pix_x[0], pix_y, pd[0], inb[0], vk, a_, b_, c_); o0.x = a_; o1.x = b_; o2.x = c_; }
-        { float a_, b_, c_; tsdf_value(vx[1], vy, vz, pix_x[1], pix_y, pd[1], inb[1], vk, a_, b_, c_); o0.y = a_; o1.y = b_; o2.y = c_; }
-        { float a_, b_, c_; tsdf_value(vx[2], vy, vz, pix_x[2], pix_y, pd[2], inb[2], vk, a_, b_, c_); o0.z = a_; o1.z = b_; o2.z = c_; }
-        { float a_, b_, c_; tsdf_value(vx[3], vy, vz, pix_x[3], pix_y, pd[3], inb[3], vk, a_, b_, c_); o0.w = a_; o1.w = b_; o2.w = c_; }
-        const int64_t e = ((int64_t)z * R + y) * R + f4i;               // o[c][z][y][x] :70-72
-        *reinterpret_cast<f4 *>(out + e) = o0;
-        *reinterpret_cast<f4 *>(out + R3 + e) = o1;
-        *reinterpret_cast<f4 *>(out + 2 * R3 + e) = o2;
-      }
-    } else {
-      // fast axis = z.  q, v_z and pix_y fixed per lane; loop over x.
-      double vz[4], q[4];
-      int pix_y[4], rowoff[4];
-      bool row_ok[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        vz[j] = oz + (double)(f4i + j) * vl;
-        q[j] = qtab[f4i + j];
-        pix_y[j] = trunc_i32(mul_then_add(nvy, q[j], cam.cy));
-        row_ok[j] = pix_y[j] >= f.t && pix_y[j] < f.b;
-        rowoff[j] = (pix_y[j] - f.t) * f.bw - f.l;
-      }
-      for (int x = 0; x < R; ++x) {
-        const double vx = ox + (double)x * vl;
-        int pix_x[4];
-        bool inb[4];
-        float pd[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pix_x[j] = trunc_i32(mul_then_add(vx, q[j], cam.cx));
-          inb[j] = row_ok[j] && pix_x[j] >= f.l && pix_x[j] < f.r;
-          pd[j] = fd[inb[j] ? rowoff[j] + pix_x[j] : 0];
-        }
-        f4 o0, o1, o2;
-        { float a_, b_, c_; tsdf_value(vx, vy, vz[0], pix_x[0], pix_y[0], pd[0], inb[0], vk, a_, b_, c_); o0.x = a_; o1.x = b_; o2.x = c_; }
-        { float a_, b_, c_; tsdf_value(vx, vy, vz[1], pix_x[1], pix_y[1], pd[1], inb[1], vk, a_, b_, c_); o0.y = a_; o1.y = b_; o2.y = c_; }
-        { float a_, b_, c_; tsdf_value(vx, vy, vz[2], pix_x[2], pix_y[2], pd[2], inb[2], vk, a_, b_, c_); o0.z = a_; o1.z = b_; o2.z = c_; }
-        { float a_, b_, c_; tsdf_value(vx, vy, vz[3], pix_x[3], pix_y[3], pd[3], inb[3], vk, a_, b_, c_); o0.w = a_; o1.w = b_; o2.w = c_; }
-        const int64_t e = ((int64_t)x * R + y) * R + f4i;               // o[c][x][y][z] tsdf_for.py:118-120
-        *reinterpret_cast<f4 *>(out + e) = o0;
-        *reinterpret_cast<f4 *>(out + R3 + e) = o1;
-        *reinterpret_cast<f4 *>(out + 2 * R3 + e) = o2;
-      }
-    }
+  vk.px0 = f.l + ab.c0;
+  vk.px1 = f.l + ab.c1;
+  vk.py0 = f.t + ab.r0;
+  vk.py1 = f.t + ab.r1;
+  if (staged) {
+    vk.stride = sw;
+    vk.base = 0;
+    phase2<LAYOUT>(g, vk, R, qtab, negtab, stage, out);
+  } else {
+    vk.stride = f.bw;
+    vk.base = ab.r0 * f.bw + ab.c0;
+    phase2<LAYOUT>(g, vk, R, qtab, negtab, f.depth, out);
   }
 }
 
