@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsdf_hip.so")
+# TSDF_HIP_LIB may point at another build of the same ABI (e.g. the stamps diagnostic build)
+LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_HERE, "libtsdf_hip.so")
 
 TSDF_LAYOUT_CZYX = 0
 TSDF_LAYOUT_CXYZ = 1

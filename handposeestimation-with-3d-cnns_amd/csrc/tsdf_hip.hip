@@ -32,16 +32,20 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "../../include/tsdf.h"
 
 namespace {
 
-constexpr int kWG = 1024;               // threads per workgroup
+constexpr int kWG = 1024;               // threads per workgroup (16 waves; needs <= 128 VGPRs)
 constexpr int kWaves = kWG / 64;        // wave64
 constexpr int kRowUnroll = 4;           // rows in flight per wave in phase 1
 constexpr int kMaxR = 128;
-constexpr int kStageFloats = 36 * 1024; // 144 KiB depth stage in LDS
+constexpr int kStageFloats = 32 * 1024; // 128 KiB depth stage in LDS (>= 181 x 181 pixels)
+constexpr int kTabR = 32;               // projection tables for R <= kTabR (2 x 4 KiB)
 constexpr int kRedStride = 12;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -53,6 +57,21 @@ struct CamK {
 };
 
 #define TSDF_INF __builtin_inff()
+
+// In-kernel timeline stamps: compiled only into the diagnostic library (make stamps), never into
+// libtsdf_hip.so.  Lane 0 of wave 0 of each workgroup records s_memrealtime (100 MHz) per phase.
+#ifdef TSDF_STAMPS
+constexpr int kStampSlots = 16, kStampFrames = 8, kStampBlocks = 512;
+__device__ unsigned long long g_stamps[kStampBlocks * kStampFrames * kStampSlots];
+#define TSDF_STAMP(iter, slot)                                                                       \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks && (iter) < kStampFrames)                      \
+      g_stamps[(blockIdx.x * kStampFrames + (iter)) * kStampSlots + (slot)] =                        \
+          __builtin_amdgcn_s_memrealtime();                                                          \
+  } while (0)
+#else
+#define TSDF_STAMP(iter, slot) do { } while (0)
+#endif
 
 // ---- raw VALU min/max (no canonicalising v_max x,x,x in front; operands here are never NaN) ----
 __device__ __forceinline__ float vmin(float a, float b) {
@@ -137,29 +156,62 @@ __device__ __forceinline__ double mul_then_add(double a, double b, double c) {
   return p + c;
 }
 
+// fl64(d / F) without the hardware division sequence (~12 dependent float64 instructions):
+// with y = RN(1/F) computed by a true division on the host, q0 = RN(d*y) is within 1 ulp of d/F,
+// r = d - q0*F is exact in one fma, and RN(q0 + r*y) is the correctly rounded quotient (Markstein's
+// correction step).  The AABB parity tests compare the result bit for bit with the oracle's division.
+__device__ __forceinline__ double div_by_focal(double d, const CamK &k) {
+  const double q0 = d * k.inv_focal;
+  const double r = __builtin_fma(-q0, k.focal, d);
+  return __builtin_fma(r, k.inv_focal, q0);
+}
+
 // A.1 x: f32( (f64(d)/F) * (x - cx) )      pre/tsdf_numba.py:91-92,95
 __device__ __forceinline__ float backproject_x(float d, int x, const CamK &k) {
-  const double q = (double)d / k.focal;
+  const double q = div_by_focal((double)d, k);
   return (float)(q * ((double)x - k.cx));
 }
 // A.1 y: f32( (-(f64(d)/F)) * (y - cy) )   pre/tsdf_numba.py:91,93,95
 __device__ __forceinline__ float backproject_y(float d, int y, const CamK &k) {
-  const double q = (double)d / k.focal;
+  const double q = div_by_focal((double)d, k);
   return (float)((-q) * ((double)y - k.cy));
 }
 
-// 4 consecutive pixels of one row starting at column c; columns >= bw read as NaN (never valid).
-__device__ __forceinline__ f4 load_row4(const float *__restrict__ rp, int c, int bw) {
+// Column plan of one lane for one 256-column chunk: which 4 columns it owns and how to load them
+// without ever touching memory outside the row (rows are packed back to back, and the last row
+// of the last frame ends the buffer).
+struct ColPlan {
+  int cl;      // clamped load column: min(c, bw-4)  -> the 16-byte load stays inside the row
+  int sh;      // c - cl in 0..3: the owned pixels are elements sh..3 of the loaded vector
+  bool own;    // c < bw: the lane owns at least one pixel of the row
+};
+
+__device__ __forceinline__ ColPlan make_plan(int c, int bw) {
+  ColPlan p;
+  p.cl = c < bw - 4 ? c : bw - 4;
+  if (p.cl < 0) p.cl = 0;
+  p.sh = c - p.cl;
+  p.own = c < bw;
+  return p;
+}
+
+// Fix-up for partial chunks (wave-uniform slow path): shift the owned pixels to elements 0.. and
+// blank (NaN = never valid) everything the lane does not own.
+__device__ __forceinline__ f4 fix_partial(f4 v, const ColPlan &p) {
   const float nan = __builtin_nanf("");
-  f4 v = {nan, nan, nan, nan};
-  if (c + 3 < bw) {
-    v = *reinterpret_cast<const f4u *>(rp + c);
-  } else {
-    if (c < bw) v.x = rp[c];
-    if (c + 1 < bw) v.y = rp[c + 1];
-    if (c + 2 < bw) v.z = rp[c + 2];
+  const float e[4] = {v.x, v.y, v.z, v.w};
+  f4 r;
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = nan;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (j + s < 4) t = (p.sh == s) ? e[j + s] : t;
+    o[j] = p.own ? t : nan;
   }
-  return v;
+  r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+  return r;
 }
 
 __device__ __forceinline__ void acc4(f4 v, float eps, float (&cmin)[4], float (&cmax)[4], float &rmin,
@@ -195,9 +247,19 @@ struct Aabb {
   bool any;
 };
 
-// ---- phase 1: AABB of all valid back-projected pixels ---------------------------------------
-__device__ __forceinline__ Aabb phase1_aabb(const Frame &f, const CamK &k, float *red) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// The 10 extents phase 1 produces (per workgroup, then per frame):
+//   [0..4] minima: cam x, cam y, depth, valid column index, valid row index   [5..9] the maxima
+constexpr int kExt = 10;
+
+// ---- phase 1: extents of all valid back-projected pixels of rows [rbeg, rend) ----------------
+// NW waves cooperate (row = rbeg + wave + NW*i); the result is wave-uniform in every thread.
+template <int NW>
+__device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, int rbeg, int rend, float *red,
+                                               float (&fin)[kExt], int stamp_iter = 0) {
+  (void)stamp_iter;
+  constexpr int kWaves = NW;  // shadows the fused kernel's wave count inside this function
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: rows are per wave
   float xmn = TSDF_INF, xmx = -TSDF_INF, ymn = TSDF_INF, ymx = -TSDF_INF;
   float dmn = TSDF_INF, dmx = -TSDF_INF;
   float cimn = TSDF_INF, cimx = -TSDF_INF, rimn = TSDF_INF, rimx = -TSDF_INF;  // indices (exact in f32)
@@ -219,41 +281,53 @@ __device__ __forceinline__ Aabb phase1_aabb(const Frame &f, const CamK &k, float
     cnt = 0;
   };
 
-  for (int cbase = 0; cbase < f.bw; cbase += 512) {
-    float cmin[2][4], cmax[2][4];
+  // one pass over the rows per 256-column chunk (lane <-> 4 consecutive columns of the chunk)
+  auto chunk_pass = [&](int cbase, auto tiny_tag) {
+    constexpr bool tiny = decltype(tiny_tag)::value;  // bw < 4: no 16-byte load fits in a row
+    float cmin[4], cmax[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        cmin[kk][j] = TSDF_INF;
-        cmax[kk][j] = -TSDF_INF;
-      }
-    const int c0 = cbase + 4 * lane, c1 = c0 + 256;
-    const bool has1 = cbase + 256 < f.bw;  // wave-uniform
+    for (int j = 0; j < 4; ++j) {
+      cmin[j] = TSDF_INF;
+      cmax[j] = -TSDF_INF;
+    }
+    const int c0 = cbase + 4 * lane;
+    const bool part = cbase + 256 > f.bw;  // the chunk is partial (wave-uniform)
+    const ColPlan p0 = make_plan(c0, f.bw);
+    const float nan = __builtin_nanf("");
 
-    for (int row0 = wave; row0 < f.bh; row0 += kWaves * kRowUnroll) {
-      f4 va[kRowUnroll], vb[kRowUnroll];
-      const float nan = __builtin_nanf("");
+    // loads of one iteration: kRowUnroll rows, UNCONDITIONAL 16-byte loads in straight-line code (rows
+    // past the band are clamped to its last row and ignored later), so that the compiler can wait
+    // with a counted vmcnt for one buffer while the other buffer's loads stay in flight
+    auto load_rows = [&](int row0, f4 (&va)[kRowUnroll]) {
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) {
         const int row = row0 + kWaves * u;
-        va[u] = f4{nan, nan, nan, nan};
-        vb[u] = f4{nan, nan, nan, nan};
-        if (row < f.bh) {
-          const float *rp = f.depth + (int64_t)row * f.bw;
-          va[u] = load_row4(rp, c0, f.bw);
-          if (has1) vb[u] = load_row4(rp, c1, f.bw);
+        const int rc = row < rend ? row : rend - 1;  // scalar
+        const float *rp = f.depth + (int64_t)rc * f.bw;
+        if constexpr (!tiny) {
+          va[u] = *reinterpret_cast<const f4u *>(rp + p0.cl);
+        } else {  // bw in 1..3: element loads, only lane 0 owns pixels
+          va[u] = f4{nan, nan, nan, nan};
+          if (c0 < f.bw) va[u].x = rp[c0];
+          if (c0 + 1 < f.bw) va[u].y = rp[c0 + 1];
+          if (c0 + 2 < f.bw) va[u].z = rp[c0 + 2];
         }
       }
+    };
+
+    auto reduce_rows = [&](int row0, const f4 (&va)[kRowUnroll]) {
       if (cnt > 64 - kRowUnroll) flush_rows();  // wave-uniform (cnt is)
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) {
         const int row = row0 + kWaves * u;
-        float rmin = TSDF_INF, rmax = -TSDF_INF;
+        f4 a = va[u];
+        if constexpr (!tiny) {
+          if (part) a = fix_partial(a, p0);
+        }
         // most 256-pixel segments hold no valid pixel at all: skip them wave-wide
-        if (__any(vmaxabs4(va[u]) >= k.eps)) acc4(va[u], k.eps, cmin[0], cmax[0], rmin, rmax);
-        if (has1 && __any(vmaxabs4(vb[u]) >= k.eps)) acc4(vb[u], k.eps, cmin[1], cmax[1], rmin, rmax);
-        if (__any(rmin <= rmax)) {
+        if (row < rend && __any(vmaxabs4(a) >= k.eps)) {
+          float rmin = TSDF_INF, rmax = -TSDF_INF;
+          acc4(a, k.eps, cmin, cmax, rmin, rmax);
           const float wmin = wave_min(rmin), wmax = wave_max(rmax);
           if (lane == cnt) {
             s_rmin = wmin;
@@ -263,28 +337,48 @@ __device__ __forceinline__ Aabb phase1_aabb(const Frame &f, const CamK &k, float
           ++cnt;
         }
       }
+    };
+
+    // two register buffers in ping-pong (no copies, so no wait is forced on the loads in flight):
+    // while one buffer is reduced the other one's kRowUnroll rows are streaming in
+    constexpr int kStep = kWaves * kRowUnroll;
+    f4 bufA[kRowUnroll], bufB[kRowUnroll];
+    load_rows(rbeg + wave, bufA);
+    for (int row0 = rbeg + wave; row0 < rend; row0 += 2 * kStep) {
+      load_rows(row0 + kStep, bufB);
+      reduce_rows(row0, bufA);
+      load_rows(row0 + 2 * kStep, bufA);
+      reduce_rows(row0 + kStep, bufB);
     }
     // column extremes of this wave's rows -> x extent; depth extremes -> z extent
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (cmin[kk][j] <= cmax[kk][j]) {
-          const int col = c0 + 256 * kk + j;
-          const int x = f.l + col;
-          const float a = backproject_x(cmin[kk][j], x, k), b = backproject_x(cmax[kk][j], x, k);
-          xmn = vmin3(xmn, a, b);
-          xmx = vmax3(xmx, a, b);
-          dmn = vmin(dmn, cmin[kk][j]);
-          dmx = vmax(dmx, cmax[kk][j]);
-          cimn = vmin(cimn, (float)col);
-          cimx = vmax(cimx, (float)col);
-        }
+    for (int j = 0; j < 4; ++j) {
+      if (cmin[j] <= cmax[j]) {
+        const int col = c0 + j;
+        const int x = f.l + col;
+        const float a = backproject_x(cmin[j], x, k), b = backproject_x(cmax[j], x, k);
+        xmn = vmin3(xmn, a, b);
+        xmx = vmax3(xmx, a, b);
+        dmn = vmin(dmn, cmin[j]);
+        dmx = vmax(dmx, cmax[j]);
+        cimn = vmin(cimn, (float)col);
+        cimx = vmax(cimx, (float)col);
       }
+    }
+  };
+  // one pass over the rows per 256-column chunk (lane <-> 4 consecutive columns of the chunk)
+  if (rbeg >= rend) {
+    // empty band
+  } else if (f.bw >= 4) {
+    for (int cbase = 0; cbase < f.bw; cbase += 256) chunk_pass(cbase, std::false_type{});
+  } else {
+    chunk_pass(0, std::true_type{});
   }
+  TSDF_STAMP(stamp_iter, 1);
   flush_rows();
+  TSDF_STAMP(stamp_iter, 2);
 
-  // wave -> LDS -> every wave reduces the 16 partials itself (no second barrier)
+  // wave -> LDS -> every wave reduces the partials itself (no second barrier)
   float part[10];
   part[0] = wave_min(xmn);
   part[1] = wave_min(ymn);
@@ -302,14 +396,32 @@ __device__ __forceinline__ Aabb phase1_aabb(const Frame &f, const CamK &k, float
     for (int i = 1; i < 10; ++i) v = (lane == i) ? part[i] : v;
     red[wave * kRedStride + lane] = v;
   }
+  TSDF_STAMP(stamp_iter, 3);
   __syncthreads();
-  float fin[10];
-  const int src = (lane & 15) * kRedStride;
+  static_assert(kWaves <= 16, "the cross-wave reduction uses one 16-lane DPP row");
+  const bool has = (lane & 15) < kWaves;
+  const int src = has ? (lane & 15) * kRedStride : 0;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) fin[i] = row0_min(red[src + i]);
+  for (int i = 0; i < 5; ++i) fin[i] = row0_min(has ? red[src + i] : TSDF_INF);
 #pragma unroll
-  for (int i = 5; i < 10; ++i) fin[i] = row0_max(red[src + i]);
+  for (int i = 5; i < 10; ++i) fin[i] = row0_max(has ? red[src + i] : -TSDF_INF);
+}
 
+// Combine up to 16 extent records (kRedStride floats apart) written by other workgroups.
+__device__ __forceinline__ void combine_extents(const float *__restrict__ rec, int count, float (&fin)[kExt]) {
+  const int lane = threadIdx.x & 63;
+  const bool has = (lane & 15) < count;
+  const int src = has ? (lane & 15) * kRedStride : 0;
+  float v[kExt];
+#pragma unroll
+  for (int i = 0; i < kExt; ++i) v[i] = rec[src + i];  // in-bounds for every lane; unused lanes masked below
+#pragma unroll
+  for (int i = 0; i < 5; ++i) fin[i] = row0_min(has ? v[i] : TSDF_INF);
+#pragma unroll
+  for (int i = 5; i < 10; ++i) fin[i] = row0_max(has ? v[i] : -TSDF_INF);
+}
+
+__device__ __forceinline__ Aabb aabb_from_extents(const float (&fin)[kExt]) {
   Aabb a;
   a.any = fin[2] <= fin[7];
   a.mn[0] = fin[0];
@@ -350,9 +462,10 @@ struct VoxK {
   double kq;   // (1/F) * it
   double ncx;  // -cx
   float eps;
-  int px0, px1, py0, py1;  // image-coordinate rectangle (inclusive) holding every valid pixel
-  int stride;              // gather source: elements per row ...
-  int base;                // ... and index of pixel (px0, py0)
+  int px0, py0;  // image coordinates of the first pixel of the rectangle holding every valid pixel
+  int dx, dy;    // its extent - 1 (inclusive upper bounds of rectangle-relative coordinates)
+  int stride;    // gather source: elements per row ...
+  int base;      // ... and index of the rectangle's first pixel
 };
 
 __device__ __forceinline__ void zero_volume(float *__restrict__ out, int R) {
@@ -362,61 +475,62 @@ __device__ __forceinline__ void zero_volume(float *__restrict__ out, int R) {
   for (int i = threadIdx.x; i < n4; i += kWG) o4[i] = z;
 }
 
-// One group of 4 voxels along the fast axis (pre/tsdf_numba.py:26-72 for each).
-// LAYOUT 0: the 4 voxels differ in x (same y, z) and use vx[0..3], vz[0], q[0], negthr[0];
-// LAYOUT 1: they differ in z (same x, y)    and use vx[0], vz[0..3], q[0..3], negthr[0..3].
-// Coordinates are pre-scaled by it = 1/trunc_dis:
-//   tx = (v_x - w_x)/trunc = v_x*it - (pix_x-cx)*(pd*kq),  tz = v_z*it + pd*it  (w_z = -pd).
-template <int LAYOUT>
-__device__ __forceinline__ void voxel_group4(const double (&vx)[4], const double vy, const double (&vz)[4],
-                                             const double (&q)[4], const float (&negthr)[4], const VoxK &k,
-                                             const float *__restrict__ src, f4 &o0, f4 &o1, f4 &o2) {
-  int pix_x[4], pix_y[4];
-  bool inb[4];
+// Projection of a voxel coordinate onto a pixel coordinate, pre/tsdf_numba.py:30-32:
+//   pix = int(v * q + c)  with q = -F / v_z   (multiply, round, add, round, truncate)
+// returned relative to the valid-pixel rectangle, or -1 when outside it (then :36 or :40 rejects).
+__device__ __forceinline__ int project_rel(double v, double q, double c, int p0, int dmax) {
+  const int rel = trunc_i32(mul_then_add(v, q, c)) - p0;
+  return (unsigned)rel <= (unsigned)dmax ? rel : -1;
+}
+
+// smallest float32 >= t  (so that for a float32 p:  p < t  <=>  p < result)
+__device__ __forceinline__ float f32_round_up(double t) {
+  float f = (float)t;
+  if ((double)f < t) f = nextafterf(f, TSDF_INF);
+  return f;
+}
+
+// Per-voxel value, pre/tsdf_numba.py:36-68, for the 4 voxels of one lane.  Coordinates are pre-scaled
+// by it = 1/trunc_dis:  tx = v_x*it - (pix_x-cx)*(pd*kq),  ty likewise,  tz = v_z*it + pd*it (w_z = -pd).
+//   ex[j], ry[j]          rectangle-relative pixel of voxel j (or -1: rejected)
+//   vxs[j], vys, vzs[j]   pre-scaled voxel centre;   negthr[j] = f32_round_up(-v_z)
+__device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry)[4], const double (&vxs)[4],
+                                              const double vys, const double (&vzs)[4],
+                                              const float (&negthr)[4], const VoxK &k,
+                                              const float *__restrict__ src, f4 &o0, f4 &o1, f4 &o2) {
   float pd[4];
-  const double nvy = -vy;
+  bool inb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int jx = LAYOUT == 0 ? j : 0, jz = LAYOUT == 0 ? 0 : j;
-    if (LAYOUT == 0 && j > 0) {
-      pix_y[j] = pix_y[0];
-    } else {
-      pix_y[j] = trunc_i32(mul_then_add(nvy, q[jz], k.cy));                 // :32
-    }
-    pix_x[j] = trunc_i32(mul_then_add(vx[jx], q[jz], k.cx));                // :31
-    // :36 restricted to the rectangle that holds every valid pixel (outside it :36 or :40 rejects)
-    inb[j] = (unsigned)(pix_x[j] - k.px0) <= (unsigned)(k.px1 - k.px0) &&
-             (unsigned)(pix_y[j] - k.py0) <= (unsigned)(k.py1 - k.py0);
-    const int idx = inb[j] ? (pix_y[j] - k.py0) * k.stride + (pix_x[j] - k.px0) + k.base : k.base;
-    pd[j] = src[idx];                                                       // :38-39
+    inb[j] = (ex[j] | ry[j]) >= 0;                                          // :36 (both in range)
+    const int idx = __mul24(ry[j], k.stride) + ex[j] + k.base;
+    pd[j] = src[inb[j] ? idx : k.base];                                     // :38-39
   }
   bool ok[4], neg[4];
   double pd64[4], tz[4];
   bool any_near = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int jz = LAYOUT == 0 ? 0 : j;
-    ok[j] = inb[j] && (__builtin_fabsf(pd[j]) >= k.eps);                    // :40
+    ok[j] = inb[j] & (__builtin_fabsf(pd[j]) >= k.eps);                     // :40
     pd64[j] = (double)pd[j];
-    tz[j] = __builtin_fma(pd64[j], k.it, vz[jz] * k.it);                    // :46,:49
-    neg[j] = pd[j] < negthr[jz];                                            // w_z > v_z  :65
-    any_near |= ok[j] && (__builtin_fabs(tz[j]) <= 1.0);
+    tz[j] = __builtin_fma(pd64[j], k.it, vzs[j]);                           // :46,:49
+    neg[j] = pd[j] < negthr[j];                                             // w_z > v_z  :65
+    any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
   }
   float r0[4], r1[4], r2[4];
   if (__any(any_near)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int jx = LAYOUT == 0 ? j : 0;
-      const double a = pd64[j] * k.kq;                                      // pd/F/trunc      :43
-      const double wx = ((double)pix_x[j] + k.ncx) * a;                     // w_x/trunc       :44
-      const double wy = (k.cy - (double)pix_y[j]) * a;                      // w_y/trunc       :45
-      const double tx = __builtin_fma(vx[jx], k.it, -wx);                   // (v_x-w_x)/trunc :47
-      const double ty = __builtin_fma(vy, k.it, -wy);                       // :48
+      const double a = pd64[j] * k.kq;                                      // pd/F/trunc         :43
+      const double dxi = (double)(ex[j] + k.px0) + k.ncx;                   // pix_x - cx         :44
+      const double dyi = (double)(ry[j] + k.py0) - k.cy;                    // pix_y - cy         :45
+      const double tx = __builtin_fma(-dxi, a, vxs[j]);                     // (v_x - w_x)/trunc  :47
+      const double ty = __builtin_fma(dyi, a, vys);                         // (v_y - w_y)/trunc  :48, w_y = -dyi*q
       const double s = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));  // dist^2 :51-52
       const bool far = !(s <= 1.0);                                         // :54 (sqrt monotone, sqrt(1)=1)
-      r0[j] = far ? 1.0f : fminf(__builtin_fabsf((float)tx), 1.0f);         // :55-60, f32 store :70-72
-      r1[j] = far ? 1.0f : fminf(__builtin_fabsf((float)ty), 1.0f);
-      r2[j] = far ? 1.0f : fminf(__builtin_fabsf((float)tz[j]), 1.0f);
+      r0[j] = far ? 1.0f : vmin(__builtin_fabsf((float)tx), 1.0f);          // :55-60, f32 store :70-72
+      r1[j] = far ? 1.0f : vmin(__builtin_fabsf((float)ty), 1.0f);
+      r2[j] = far ? 1.0f : vmin(__builtin_fabsf((float)tz[j]), 1.0f);
     }
   } else {
     // every voxel of this wave is rejected or beyond the truncation distance along z alone:
@@ -428,27 +542,37 @@ __device__ __forceinline__ void voxel_group4(const double (&vx)[4], const double
         *p2 = reinterpret_cast<float *>(&o2);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float sg = neg[j] ? -1.0f : 1.0f;
-    p0[j] = ok[j] ? sg * r0[j] : 0.0f;                                      // :33-41, :65-68
-    p1[j] = ok[j] ? sg * r1[j] : 0.0f;
-    p2[j] = ok[j] ? sg * r2[j] : 0.0f;
+    const unsigned sg = neg[j] ? 0x80000000u : 0u;                          // sign :65-68
+    p0[j] = ok[j] ? __uint_as_float(__float_as_uint(r0[j]) | sg) : 0.0f;    // zero if rejected :33-41
+    p1[j] = ok[j] ? __uint_as_float(__float_as_uint(r1[j]) | sg) : 0.0f;
+    p2[j] = ok[j] ? __uint_as_float(__float_as_uint(r2[j]) | sg) : 0.0f;
   }
 }
 
-// smallest float32 >= t  (so that for a float32 p:  p < t  <=>  p < result)
-__device__ __forceinline__ float f32_round_up(double t) {
-  float f = (float)t;
-  if ((double)f < t) f = nextafterf(f, TSDF_INF);
-  return f;
+// LDS-resident per-frame tables.  The pixel a voxel projects to factorises: pix_x depends on (x, z)
+// only and pix_y on (y, z) only, so for R <= kTabR both are tabulated once per frame (R*R entries
+// each, one pair per thread) instead of 3 float64 operations + a range test per voxel.
+struct ZEntry {
+  double q;      // -F / v_z                     :30
+  double vzs;    // v_z / trunc_dis
+  float negthr;  // f32_round_up(-v_z)
+  float pad;
+};
+
+// table index of (fast, slow) coordinates: the 4 entries a lane needs are contiguous
+template <int LAYOUT>
+__device__ __forceinline__ int tab_index(int x_or_y, int z, int R) {
+  return LAYOUT == 0 ? z * R + x_or_y : x_or_y * R + z;
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ void phase2(const Grid &g, const VoxK &vk, int R, const double *qtab,
-                                       const float *negtab, const float *__restrict__ src,
+__device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R,
+                                       const ZEntry *ztab, const int *pxtab, const int *pytab,
+                                       const bool use_tab, const float *__restrict__ src,
                                        float *__restrict__ out) {
   const int tid = threadIdx.x;
   const double vl = (double)g.voxel_len;
-  const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
+  const double ox = (double)g.ori[0], oy = (double)g.ori[1];
   const int R4 = R / 4;
   const int G = R * R4;  // groups of 4 voxels per slow-axis slice
   const int64_t R3 = (int64_t)R * R * R;
@@ -470,33 +594,70 @@ __device__ __forceinline__ void phase2(const Grid &g, const VoxK &vk, int R, con
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
     const double vy = oy + (double)y * vl;                                  // :27
-    double vx[4], vz[4], q[4];
-    float negthr[4];
+    const double vys = vy * vk.it;
     if constexpr (LAYOUT == 0) {
+      // lanes run along x: v_x fixed per lane, loop over z
+      double vx[4], vxs[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) vx[j] = ox + (double)(f4i + j) * vl;      // :26
+      for (int j = 0; j < 4; ++j) {
+        vx[j] = ox + (double)(f4i + j) * vl;                                // :26
+        vxs[j] = vx[j] * vk.it;
+      }
       for (int z = s0; z < R; z += sstep) {
-        vz[0] = oz + (double)z * vl;                                        // :28
-        q[0] = qtab[z];
-        negthr[0] = negtab[z];
+        const ZEntry ze = ztab[z];
+        int ex[4], ry[4];
+        if (use_tab) {
+          const int4 e = *reinterpret_cast<const int4 *>(pxtab + z * R + f4i);
+          ex[0] = e.x; ex[1] = e.y; ex[2] = e.z; ex[3] = e.w;
+          ry[0] = pytab[z * R + y];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ex[j] = project_rel(vx[j], ze.q, cam.cx, vk.px0, vk.dx);  // :31
+          ry[0] = project_rel(-vy, ze.q, cam.cy, vk.py0, vk.dy);                                 // :32
+        }
+        ry[1] = ry[2] = ry[3] = ry[0];
+        const double vzs[4] = {ze.vzs, ze.vzs, ze.vzs, ze.vzs};
+        const float negthr[4] = {ze.negthr, ze.negthr, ze.negthr, ze.negthr};
         f4 o0, o1, o2;
-        voxel_group4<0>(vx, vy, vz, q, negthr, vk, src, o0, o1, o2);
+        voxel_values4(ex, ry, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
         const int64_t e = ((int64_t)z * R + y) * R + f4i;                   // o[c][z][y][x] :70-72
         *reinterpret_cast<f4 *>(out + e) = o0;
         *reinterpret_cast<f4 *>(out + R3 + e) = o1;
         *reinterpret_cast<f4 *>(out + 2 * R3 + e) = o2;
       }
     } else {
+      // lanes run along z: q, v_z and pix_y fixed per lane, loop over x
+      double q[4], vzs[4];
+      float negthr[4];
+      int ry[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        vz[j] = oz + (double)(f4i + j) * vl;
-        q[j] = qtab[f4i + j];
-        negthr[j] = negtab[f4i + j];
+        const ZEntry ze = ztab[f4i + j];
+        q[j] = ze.q;
+        vzs[j] = ze.vzs;
+        negthr[j] = ze.negthr;
+      }
+      if (use_tab) {
+        const int4 e = *reinterpret_cast<const int4 *>(pytab + y * R + f4i);
+        ry[0] = e.x; ry[1] = e.y; ry[2] = e.z; ry[3] = e.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ry[j] = project_rel(-vy, q[j], cam.cy, vk.py0, vk.dy);
       }
       for (int x = s0; x < R; x += sstep) {
-        vx[0] = ox + (double)x * vl;
+        const double vx = ox + (double)x * vl;
+        const double vx1 = vx * vk.it;
+        const double vxs[4] = {vx1, vx1, vx1, vx1};
+        int ex[4];
+        if (use_tab) {
+          const int4 e = *reinterpret_cast<const int4 *>(pxtab + x * R + f4i);
+          ex[0] = e.x; ex[1] = e.y; ex[2] = e.z; ex[3] = e.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ex[j] = project_rel(vx, q[j], cam.cx, vk.px0, vk.dx);
+        }
         f4 o0, o1, o2;
-        voxel_group4<1>(vx, vy, vz, q, negthr, vk, src, o0, o1, o2);
+        voxel_values4(ex, ry, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
         const int64_t e = ((int64_t)x * R + y) * R + f4i;                   // o[c][x][y][z] tsdf_for.py:118-120
         *reinterpret_cast<f4 *>(out + e) = o0;
         *reinterpret_cast<f4 *>(out + R3 + e) = o1;
@@ -506,23 +667,36 @@ __device__ __forceinline__ void phase2(const Grid &g, const VoxK &vk, int R, con
   }
 }
 
-template <int RT, int LAYOUT>
-__global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
+struct FrameHdr {
+  int l, t, r, b;
+  int64_t off0, off1;
+};
+
+__device__ __forceinline__ FrameHdr load_hdr(const int64_t *__restrict__ offsets,
+                                             const int32_t *__restrict__ headers, int frame) {
+  const int32_t *h = headers + 6 * (int64_t)frame;
+  FrameHdr fh;
+  fh.l = h[2];
+  fh.t = h[3];
+  fh.r = h[4];
+  fh.b = h[5];
+  fh.off0 = offsets[frame];
+  fh.off1 = offsets[frame + 1];
+  return fh;
+}
+
+// Kernel 1 of the two-launch path: per-frame extents by row bands, at high occupancy.
+// Workgroup (frame, band) reduces rows [bh*band/S, bh*(band+1)/S) and leaves its kExt extents in the
+// first floats of the frame's OWN output volume (band * kRedStride); kernel 2 combines the S records
+// before it overwrites them.  No workspace, no atomics, nothing to initialise.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void tsdf_extents_kernel(
     const float *__restrict__ depth, const int64_t *__restrict__ offsets,
-    const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
-    float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
-    float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
-    int aabb_only) {
-  __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
-  __shared__ double qtab[kMaxR];
-  __shared__ float negtab[kMaxR];
-  __shared__ float red[kWaves * kRedStride];
-
-  const int R = RT ? RT : Rrt;
-  const int frame = blockIdx.x;
+    const int32_t *__restrict__ headers, int n, int S, CamK cam, float *__restrict__ out_tsdf,
+    int64_t vol_floats) {
+  __shared__ float red[NW * kRedStride];
+  const int frame = blockIdx.x / S, band = blockIdx.x - frame * S;
   if (frame >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
   const int32_t *h = headers + 6 * (int64_t)frame;
   Frame f;
   f.l = h[2];
@@ -533,122 +707,224 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
   f.bh = f.b - f.t;
   const int64_t off0 = offsets[frame], off1 = offsets[frame + 1];
   f.depth = depth + off0;
-  float *out = out_tsdf ? out_tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
+  float fin[kExt];
+#pragma unroll
+  for (int i = 0; i < kExt; ++i) fin[i] = i < 5 ? TSDF_INF : -TSDF_INF;
+  if (f.bw > 0 && f.bh > 0 && (int64_t)f.bw * (int64_t)f.bh == off1 - off0) {  // block-uniform
+    const int rbeg = (int)((int64_t)f.bh * band / S), rend = (int)((int64_t)f.bh * (band + 1) / S);
+    phase1_extents<NW>(f, cam, rbeg, rend, red, fin);
+  }
+  if (threadIdx.x < kExt) {
+    float v = fin[0];
+#pragma unroll
+    for (int i = 1; i < kExt; ++i) v = ((int)threadIdx.x == i) ? fin[i] : v;
+    out_tsdf[(int64_t)frame * vol_floats + band * kRedStride + threadIdx.x] = v;
+  }
+}
 
-  int status = TSDF_FRAME_OK;
-  Aabb ab;
-  ab.any = false;
-  ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
-  ab.c0 = ab.r0 = 0;
-  ab.c1 = ab.r1 = -1;
-  Grid g;
-  g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
-  g.max_l = g.voxel_len = g.trunc = 0.f;
-  g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
+// Persistent kernel: gridDim.x workgroups (one per CU) walk the frames blockIdx.x, +gridDim.x, ...
+// S == 0: fused form, phase 1 runs here.  S > 0: kernel 2 of the two-launch path, the extents come
+// from the S records tsdf_extents_kernel left in the frame's output volume.
+template <int RT, int LAYOUT>
+__global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
+    const float *__restrict__ depth, const int64_t *__restrict__ offsets,
+    const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
+    float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
+    float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
+    int aabb_only, int S) {
+  __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
+  __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
+  __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
+  __shared__ __attribute__((aligned(16))) ZEntry ztab[kMaxR];
+  __shared__ float red[kWaves * kRedStride];
 
-  if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != off1 - off0) {
-    status = TSDF_FRAME_BAD_HEADER;  // block-uniform
-  } else {
-    ab = phase1_aabb(f, cam, red);
-    if (!ab.any) {
-      status = TSDF_FRAME_DEGENERATE;
-      ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+  const int R = RT ? RT : Rrt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int frame = blockIdx.x;
+  if (frame >= n) return;
+  FrameHdr fh = load_hdr(offsets, headers, frame);
+
+  int iter = 0;
+  (void)iter;
+  for (; frame < n; frame += gridDim.x, ++iter) {
+    TSDF_STAMP(iter, 0);
+    // the next frame's header/offsets are requested now, a whole frame ahead of their use
+    const int nframe = frame + gridDim.x;
+    FrameHdr nfh = fh;
+    if (nframe < n) nfh = load_hdr(offsets, headers, nframe);
+
+    Frame f;
+    f.l = fh.l;
+    f.t = fh.t;
+    f.r = fh.r;
+    f.b = fh.b;
+    f.bw = f.r - f.l;
+    f.bh = f.b - f.t;
+    f.depth = depth + fh.off0;
+    float *out = out_tsdf ? out_tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
+
+    int status = TSDF_FRAME_OK;
+    Aabb ab;
+    ab.any = false;
+    ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+    ab.c0 = ab.r0 = 0;
+    ab.c1 = ab.r1 = -1;
+    Grid g;
+    g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
+    g.max_l = g.voxel_len = g.trunc = 0.f;
+    g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
+
+    if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != fh.off1 - fh.off0) {
+      status = TSDF_FRAME_BAD_HEADER;  // block-uniform
     } else {
-      g = glue(ab.mn, ab.mx, R, cam);
-      if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF)) {
+      float fin[kExt];
+      if (S > 0) {
+        combine_extents(out, S, fin);  // every wave reads the records before the staging barrier below
+      } else {
+        phase1_extents<kWaves>(f, cam, 0, f.bh, red, fin, iter);  // contains one __syncthreads()
+      }
+      ab = aabb_from_extents(fin);
+      TSDF_STAMP(iter, 4);
+      if (!ab.any) {
         status = TSDF_FRAME_DEGENERATE;
-        g.max_l = g.voxel_len = g.trunc = 0.f;
+        ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+      } else {
+        g = glue(ab.mn, ab.mx, R, cam);
+        if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF)) {
+          status = TSDF_FRAME_DEGENERATE;
+          g.max_l = g.voxel_len = g.trunc = 0.f;
+        }
       }
     }
-  }
 
-  if (tid == 0) {
-    if (out_max_l) out_max_l[frame] = g.max_l;
-    if (out_mid_p) {
-      out_mid_p[3 * (int64_t)frame + 0] = g.mid[0];
-      out_mid_p[3 * (int64_t)frame + 1] = g.mid[1];
-      out_mid_p[3 * (int64_t)frame + 2] = g.mid[2];
-    }
-    if (out_status) out_status[frame] = status;
-    if (out_aabb) {
-      float *a = out_aabb + 6 * (int64_t)frame;
-      a[0] = ab.mn[0]; a[1] = ab.mn[1]; a[2] = ab.mn[2];
-      a[3] = ab.mx[0]; a[4] = ab.mx[1]; a[5] = ab.mx[2];
-    }
-    if (out_grid) {
-      float *q = out_grid + 8 * (int64_t)frame;
-      q[0] = g.mid[0]; q[1] = g.mid[1]; q[2] = g.mid[2];
-      q[3] = g.max_l; q[4] = g.voxel_len; q[5] = g.trunc; q[6] = 0.f; q[7] = 0.f;
-    }
-    if (out_ori) {
-      float *q = out_ori + 3 * (int64_t)frame;
-      q[0] = g.ori[0]; q[1] = g.ori[1]; q[2] = g.ori[2];
-    }
-  }
-  if (aabb_only || !out) return;
-  if (status != TSDF_FRAME_OK) {
-    zero_volume(out, R);
-    return;
-  }
-
-  // ---- per-z tables (true divisions, once per z) ----
-  const double vl = (double)g.voxel_len;
-  if (tid < R) {
-    const double v_z = (double)g.ori[2] + (double)tid * vl;  // :28
-    qtab[tid] = -cam.focal / v_z;                            // :30
-    negtab[tid] = f32_round_up(-v_z);                        // pd < -v_z  <=>  w_z > v_z  (:65)
-  }
-
-  // ---- stage the rectangle of valid pixels into LDS ----
-  const int sw = ab.c1 - ab.c0 + 1, sh = ab.r1 - ab.r0 + 1;
-  const bool staged = (int64_t)sw * sh <= kStageFloats;  // block-uniform
-  if (staged) {
-    const float *__restrict__ srcp = f.depth + (int64_t)ab.r0 * f.bw + ab.c0;
-    for (int r0 = wave; r0 < sh; r0 += kWaves * 4) {
-      for (int cb = 0; cb < sw; cb += 256) {
-        float v[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
-            v[u][kk] = (r < sh && c < sw) ? srcp[(int64_t)r * f.bw + c] : 0.f;
-          }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
-            if (r < sh && c < sw) stage[r * sw + c] = v[u][kk];
-          }
+    if (tid == 0) {
+      if (out_max_l) out_max_l[frame] = g.max_l;
+      if (out_mid_p) {
+        out_mid_p[3 * (int64_t)frame + 0] = g.mid[0];
+        out_mid_p[3 * (int64_t)frame + 1] = g.mid[1];
+        out_mid_p[3 * (int64_t)frame + 2] = g.mid[2];
+      }
+      if (out_status) out_status[frame] = status;
+      if (out_aabb) {
+        float *a = out_aabb + 6 * (int64_t)frame;
+        a[0] = ab.mn[0]; a[1] = ab.mn[1]; a[2] = ab.mn[2];
+        a[3] = ab.mx[0]; a[4] = ab.mx[1]; a[5] = ab.mx[2];
+      }
+      if (out_grid) {
+        float *q = out_grid + 8 * (int64_t)frame;
+        q[0] = g.mid[0]; q[1] = g.mid[1]; q[2] = g.mid[2];
+        q[3] = g.max_l; q[4] = g.voxel_len; q[5] = g.trunc; q[6] = 0.f; q[7] = 0.f;
+      }
+      if (out_ori) {
+        float *q = out_ori + 3 * (int64_t)frame;
+        q[0] = g.ori[0]; q[1] = g.ori[1]; q[2] = g.ori[2];
       }
     }
-  }
-  __syncthreads();
 
-  VoxK vk;
-  vk.cx = cam.cx;
-  vk.cy = cam.cy;
-  vk.it = 1.0 / (double)g.trunc;
-  vk.kq = cam.inv_focal * vk.it;
-  vk.ncx = -cam.cx;
-  vk.eps = cam.eps;
-  vk.px0 = f.l + ab.c0;
-  vk.px1 = f.l + ab.c1;
-  vk.py0 = f.t + ab.r0;
-  vk.py1 = f.t + ab.r1;
-  if (staged) {
-    vk.stride = sw;
-    vk.base = 0;
-    phase2<LAYOUT>(g, vk, R, qtab, negtab, stage, out);
-  } else {
-    vk.stride = f.bw;
-    vk.base = ab.r0 * f.bw + ab.c0;
-    phase2<LAYOUT>(g, vk, R, qtab, negtab, f.depth, out);
+    if (!aabb_only && out) {
+      if (status != TSDF_FRAME_OK) {
+        zero_volume(out, R);
+      } else {
+        VoxK vk;
+        vk.cx = cam.cx;
+        vk.cy = cam.cy;
+        vk.it = 1.0 / (double)g.trunc;
+        vk.kq = cam.inv_focal * vk.it;
+        vk.ncx = -cam.cx;
+        vk.eps = cam.eps;
+        vk.px0 = f.l + ab.c0;
+        vk.py0 = f.t + ab.r0;
+        vk.dx = ab.c1 - ab.c0;
+        vk.dy = ab.r1 - ab.r0;
+
+        // ---- per-frame tables (true divisions; one (x,z)/(y,z) pair per thread) ----
+        const double vl = (double)g.voxel_len;
+        const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
+        if (tid < R) {
+          const double v_z = oz + (double)tid * vl;  // :28
+          ZEntry ze;
+          ze.q = -cam.focal / v_z;                   // :30
+          ze.vzs = v_z * vk.it;
+          ze.negthr = f32_round_up(-v_z);            // pd < -v_z  <=>  w_z > v_z  (:65)
+          ze.pad = 0.f;
+          ztab[tid] = ze;
+        }
+        TSDF_STAMP(iter, 5);
+        const bool use_tab = R <= kTabR;  // block-uniform
+        if (use_tab) {
+          for (int e = tid; e < R * R; e += kWG) {
+            const int z = e / R, i = e - z * R;
+            const double q = -cam.focal / (oz + (double)z * vl);                              // :30
+            const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
+            pxtab[tab_index<LAYOUT>(i, z, R)] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);    // :31
+            pytab[tab_index<LAYOUT>(i, z, R)] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);   // :32
+          }
+        }
+
+        TSDF_STAMP(iter, 6);
+        // ---- stage the rectangle of valid pixels into LDS ----
+        const int sw = vk.dx + 1, sh = vk.dy + 1;
+        const bool staged = (int64_t)sw * sh <= kStageFloats;  // block-uniform
+        if (staged) {
+          const float *__restrict__ srcp = f.depth + (int64_t)ab.r0 * f.bw + ab.c0;
+          for (int r0 = wave; r0 < sh; r0 += kWaves * 4) {
+            for (int cb = 0; cb < sw; cb += 256) {
+              float v[4][4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
+                  v[u][kk] = (r < sh && c < sw) ? srcp[(int64_t)r * f.bw + c] : 0.f;
+                }
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
+                  if (r < sh && c < sw) stage[r * sw + c] = v[u][kk];
+                }
+            }
+          }
+        }
+        TSDF_STAMP(iter, 7);
+        __syncthreads();
+        TSDF_STAMP(iter, 8);
+        if (staged) {
+          vk.stride = sw;
+          vk.base = 0;
+          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, stage, out);
+        } else {
+          vk.stride = f.bw;
+          vk.base = ab.r0 * f.bw + ab.c0;
+          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, f.depth, out);
+        }
+      }
+    }
+    TSDF_STAMP(iter, 9);
+    fh = nfh;
+    // LDS reuse across frames: the stage/tables of the next frame may only be written once every wave
+    // has left this frame's phase 2.  In the fused form the next phase-1 barrier provides that for
+    // frames that ran phase 2; otherwise (no phase 1 here, or phase 2 skipped) close the frame here.
+    if (S > 0 || aabb_only || !out || status != TSDF_FRAME_OK) __syncthreads();
   }
 }
 
 const tsdf_cam kDefaultCam = {241.42, 160.0, 120.0, 1.0f, 3.0f};
+
+// CU count of the current device (cached per device id; a racing first call computes the same value)
+int num_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev] = v;
+  }
+  return cached[dev];
+}
 
 int check_device() {
   int dev = 0;
@@ -659,12 +935,47 @@ int check_device() {
   return TSDF_OK;
 }
 
+constexpr int kExtWaves = 4;    // kernel 1: 256-thread workgroups
+constexpr int kMaxBands = 16;   // extent records per frame (one 16-lane DPP row combines them)
+
+// row bands per frame for kernel 1: enough workgroups to fill the chip twice, 4 at batch >= 512
+int bands_for(int n) {
+  int s = (2 * 8 * num_cus() + n - 1) / n;  // ~8 workgroups of 256 threads per CU, two rounds
+  if (s < 4) s = 4;
+  if (s > kMaxBands) s = kMaxBands;
+  return s;
+}
+
 template <int RT, int LAYOUT>
 hipError_t launch(hipStream_t s, const float *d, const int64_t *o, const int32_t *h, int n, int R, CamK ck,
                   float *t, float *ml, float *mp, int32_t *st, float *ab, float *gr, float *orr,
                   int aabb_only) {
-  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT>), dim3(n), dim3(kWG), 0, s, d, o, h, n, R, ck, t, ml,
-                     mp, st, ab, gr, orr, aabb_only);
+  const int grid = n < num_cus() ? n : num_cus();  // persistent: one workgroup per CU
+  int S = 0;
+  const int64_t vol = (int64_t)3 * R * R * R;
+#ifdef TSDF_STAMPS
+  const bool two_launch = getenv("TSDF_DEBUG_FUSED") == nullptr;
+#else
+  const bool two_launch = true;
+#endif
+  if (two_launch && !aabb_only && t) {
+    // two launches: extents at high occupancy, then the LDS-staged voxelization
+    S = bands_for(n);
+    while ((int64_t)S * kRedStride > vol) S /= 2;  // the records live inside the frame's own volume
+    if (S >= 1) {
+      hipLaunchKernelGGL((tsdf_extents_kernel<kExtWaves>), dim3((unsigned)n * (unsigned)S), dim3(kExtWaves * 64),
+                         0, s, d, o, h, n, S, ck, t, vol);
+      hipError_t e1 = hipGetLastError();
+      if (e1 != hipSuccess) return e1;
+    } else {
+      S = 0;
+    }
+  }
+#ifdef TSDF_STAMPS
+  if (S > 0 && getenv("TSDF_DEBUG_SKIP_K2")) return hipGetLastError();  // diagnostic build only
+#endif
+  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT>), dim3(grid), dim3(kWG), 0, s, d, o, h, n, R, ck, t, ml,
+                     mp, st, ab, gr, orr, aabb_only, S);
   return hipGetLastError();
 }
 
@@ -738,5 +1049,17 @@ int tsdf_aabb_hip(const float *d_depth, const int64_t *d_offsets, const int32_t 
   return run(d_depth, d_offsets, d_headers, n, R, cam, TSDF_LAYOUT_CZYX, hip_stream, nullptr, nullptr,
              nullptr, d_out_status, d_out_aabb, d_out_grid, d_out_ori, 1);
 }
+
+#ifdef TSDF_STAMPS
+// Diagnostic library only: copy the stamp array to the host (synchronises the device).
+int tsdf_debug_read_stamps(unsigned long long *host_out, int count) {
+  const int total = kStampBlocks * kStampFrames * kStampSlots;
+  if (count > total) count = total;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * count) != hipSuccess)
+    return -1;
+  return count;
+}
+#endif
 
 }  // extern "C"
