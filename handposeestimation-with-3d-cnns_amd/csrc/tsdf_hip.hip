@@ -40,8 +40,13 @@
 
 namespace {
 
-constexpr int kWG = 1024;               // threads per workgroup (16 waves; needs <= 128 VGPRs)
-constexpr int kWaves = kWG / 64;        // wave64
+constexpr int kWG = 1024;               // threads per workgroup (16 wave64; needs <= 128 VGPRs)
+#ifndef TSDF_GROUPS
+#define TSDF_GROUPS 2
+#endif
+constexpr int kGroups = TSDF_GROUPS;    // half-workgroups: each walks its own frames, see the kernel
+constexpr int kGW = kWG / kGroups;      // threads per group
+constexpr int kGWaves = kGW / 64;       // waves per group
 constexpr int kRowUnroll = 4;           // rows in flight per wave in phase 1
 constexpr int kMaxR = 128;
 constexpr int kStageFloats = 32 * 1024; // 128 KiB depth stage in LDS (>= 181 x 181 pixels)
@@ -65,7 +70,7 @@ constexpr int kStampSlots = 16, kStampFrames = 8, kStampBlocks = 512;
 __device__ unsigned long long g_stamps[kStampBlocks * kStampFrames * kStampSlots];
 #define TSDF_STAMP(iter, slot)                                                                       \
   do {                                                                                               \
-    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks && (iter) < kStampFrames)                      \
+    if ((threadIdx.x & (kGW - 1)) == 0 && blockIdx.x < kStampBlocks && (iter) < kStampFrames)                      \
       g_stamps[(blockIdx.x * kStampFrames + (iter)) * kStampSlots + (slot)] =                        \
           __builtin_amdgcn_s_memrealtime();                                                          \
   } while (0)
@@ -253,13 +258,14 @@ constexpr int kExt = 10;
 
 // ---- phase 1: extents of all valid back-projected pixels of rows [rbeg, rend) ----------------
 // NW waves cooperate (row = rbeg + wave + NW*i); the result is wave-uniform in every thread.
-template <int NW>
+// `wave` is the (scalar) index of this wave among the NW cooperating waves, `sync` their barrier.
+template <int NW, typename SYNC>
 __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, int rbeg, int rend, float *red,
-                                               float (&fin)[kExt], int stamp_iter = 0) {
+                                               float (&fin)[kExt], const int wave, SYNC sync,
+                                               int stamp_iter = 0) {
   (void)stamp_iter;
-  constexpr int kWaves = NW;  // shadows the fused kernel's wave count inside this function
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: rows are per wave
+  constexpr int kWaves = NW;
+  const int lane = threadIdx.x & 63;
   float xmn = TSDF_INF, xmx = -TSDF_INF, ymn = TSDF_INF, ymx = -TSDF_INF;
   float dmn = TSDF_INF, dmx = -TSDF_INF;
   float cimn = TSDF_INF, cimx = -TSDF_INF, rimn = TSDF_INF, rimx = -TSDF_INF;  // indices (exact in f32)
@@ -397,7 +403,7 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
     red[wave * kRedStride + lane] = v;
   }
   TSDF_STAMP(stamp_iter, 3);
-  __syncthreads();
+  sync();
   static_assert(kWaves <= 16, "the cross-wave reduction uses one 16-lane DPP row");
   const bool has = (lane & 15) < kWaves;
   const int src = has ? (lane & 15) * kRedStride : 0;
@@ -405,20 +411,6 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
   for (int i = 0; i < 5; ++i) fin[i] = row0_min(has ? red[src + i] : TSDF_INF);
 #pragma unroll
   for (int i = 5; i < 10; ++i) fin[i] = row0_max(has ? red[src + i] : -TSDF_INF);
-}
-
-// Combine up to 16 extent records (kRedStride floats apart) written by other workgroups.
-__device__ __forceinline__ void combine_extents(const float *__restrict__ rec, int count, float (&fin)[kExt]) {
-  const int lane = threadIdx.x & 63;
-  const bool has = (lane & 15) < count;
-  const int src = has ? (lane & 15) * kRedStride : 0;
-  float v[kExt];
-#pragma unroll
-  for (int i = 0; i < kExt; ++i) v[i] = rec[src + i];  // in-bounds for every lane; unused lanes masked below
-#pragma unroll
-  for (int i = 0; i < 5; ++i) fin[i] = row0_min(has ? v[i] : TSDF_INF);
-#pragma unroll
-  for (int i = 5; i < 10; ++i) fin[i] = row0_max(has ? v[i] : -TSDF_INF);
 }
 
 __device__ __forceinline__ Aabb aabb_from_extents(const float (&fin)[kExt]) {
@@ -468,11 +460,11 @@ struct VoxK {
   int base;      // ... and index of the rectangle's first pixel
 };
 
-__device__ __forceinline__ void zero_volume(float *__restrict__ out, int R) {
+__device__ __forceinline__ void zero_volume(float *__restrict__ out, int R, int gtid) {
   const int n4 = 3 * R * R * R / 4;
   f4 *o4 = reinterpret_cast<f4 *>(out);
   const f4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < n4; i += kWG) o4[i] = z;
+  for (int i = gtid; i < n4; i += kGW) o4[i] = z;
 }
 
 // Projection of a voxel coordinate onto a pixel coordinate, pre/tsdf_numba.py:30-32:
@@ -569,8 +561,7 @@ template <int LAYOUT>
 __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                        const ZEntry *ztab, const int *pxtab, const int *pytab,
                                        const bool use_tab, const float *__restrict__ src,
-                                       float *__restrict__ out) {
-  const int tid = threadIdx.x;
+                                       float *__restrict__ out, const int tid) {  // tid within the group
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1];
   const int R4 = R / 4;
@@ -579,14 +570,14 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
 
   // slow axis s (z for LAYOUT 0, x for LAYOUT 1); group gi -> (y, fast4)
   int g0, gstep, s0, sstep;
-  if (G <= kWG && (kWG % G) == 0) {
+  if (G <= kGW && (kGW % G) == 0) {
     g0 = tid % G;
-    gstep = G;  // one group per thread, kWG/G slices at a time
+    gstep = G;  // one group of 4 voxels per thread, kGW/G slices at a time
     s0 = tid / G;
-    sstep = kWG / G;
+    sstep = kGW / G;
   } else {
     g0 = tid;
-    gstep = kWG;
+    gstep = kGW;
     s0 = 0;
     sstep = 1;
   }
@@ -667,6 +658,29 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
   }
 }
 
+// ---- synchronisation inside one half-workgroup (group) -------------------------------------------
+// s_barrier spans all 16 waves, so the 8 waves of a group meet on an LDS counter instead: monotonic
+// count, lane 0 of each wave adds 1 and polls until the group's epoch target is reached.  LDS
+// operations of a wave execute in order, so everything a wave wrote to LDS before its arrival is
+// visible to whoever sees the count.  Only LDS is ordered here (no vmcnt wait: output stores stay
+// in flight across these barriers).
+struct GroupCtl {
+  int bar[kGroups];
+  int lock;  // 0 free, 1 held: the LDS stage + tables are one resource the two groups take turns on
+  int pad;
+};
+
+__device__ __forceinline__ void group_barrier(int *cnt, int &target) {
+  target += kGWaves;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
 struct FrameHdr {
   int l, t, r, b;
   int64_t off0, off1;
@@ -685,72 +699,51 @@ __device__ __forceinline__ FrameHdr load_hdr(const int64_t *__restrict__ offsets
   return fh;
 }
 
-// Kernel 1 of the two-launch path: per-frame extents by row bands, at high occupancy.
-// Workgroup (frame, band) reduces rows [bh*band/S, bh*(band+1)/S) and leaves its kExt extents in the
-// first floats of the frame's OWN output volume (band * kRedStride); kernel 2 combines the S records
-// before it overwrites them.  No workspace, no atomics, nothing to initialise.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void tsdf_extents_kernel(
-    const float *__restrict__ depth, const int64_t *__restrict__ offsets,
-    const int32_t *__restrict__ headers, int n, int S, CamK cam, float *__restrict__ out_tsdf,
-    int64_t vol_floats) {
-  __shared__ float red[NW * kRedStride];
-  const int frame = blockIdx.x / S, band = blockIdx.x - frame * S;
-  if (frame >= n) return;
-  const int32_t *h = headers + 6 * (int64_t)frame;
-  Frame f;
-  f.l = h[2];
-  f.t = h[3];
-  f.r = h[4];
-  f.b = h[5];
-  f.bw = f.r - f.l;
-  f.bh = f.b - f.t;
-  const int64_t off0 = offsets[frame], off1 = offsets[frame + 1];
-  f.depth = depth + off0;
-  float fin[kExt];
-#pragma unroll
-  for (int i = 0; i < kExt; ++i) fin[i] = i < 5 ? TSDF_INF : -TSDF_INF;
-  if (f.bw > 0 && f.bh > 0 && (int64_t)f.bw * (int64_t)f.bh == off1 - off0) {  // block-uniform
-    const int rbeg = (int)((int64_t)f.bh * band / S), rend = (int)((int64_t)f.bh * (band + 1) / S);
-    phase1_extents<NW>(f, cam, rbeg, rend, red, fin);
-  }
-  if (threadIdx.x < kExt) {
-    float v = fin[0];
-#pragma unroll
-    for (int i = 1; i < kExt; ++i) v = ((int)threadIdx.x == i) ? fin[i] : v;
-    out_tsdf[(int64_t)frame * vol_floats + band * kRedStride + threadIdx.x] = v;
-  }
-}
-
-// Persistent kernel: gridDim.x workgroups (one per CU) walk the frames blockIdx.x, +gridDim.x, ...
-// S == 0: fused form, phase 1 runs here.  S > 0: kernel 2 of the two-launch path, the extents come
-// from the S records tsdf_extents_kernel left in the frame's output volume.
+// Persistent kernel, one 1024-thread workgroup per CU.  Its two 512-thread groups each walk their
+// own frames  (frame = blockIdx.x + gridDim.x * (group + 2*i))  through
+//     stream rows -> extents -> glue        (no shared resource; the memory-bound part)
+//     [ tables -> stage -> phase 2 ]        (holds the LDS stage; the VALU/store-bound part)
+// and take turns on the single 128 KiB LDS stage, so one group's row streaming overlaps the other
+// group's voxel arithmetic and stores on the same CU.
 template <int RT, int LAYOUT>
 __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     const float *__restrict__ depth, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
     float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
     float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
-    int aabb_only, int S) {
+    int aabb_only) {
   __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
   __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) ZEntry ztab[kMaxR];
-  __shared__ float red[kWaves * kRedStride];
+  __shared__ float red_all[kGroups][kGWaves * kRedStride];
+  __shared__ GroupCtl ctl;
 
   const int R = RT ? RT : Rrt;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int frame = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, gtid = tid & (kGW - 1);
+  const int group = __builtin_amdgcn_readfirstlane(tid / kGW);
+  const int gwave = __builtin_amdgcn_readfirstlane((tid >> 6) & (kGWaves - 1));
+  float *red = red_all[group];
+
+  if (tid == 0) {
+    for (int i = 0; i < kGroups; ++i) ctl.bar[i] = 0;
+    ctl.lock = 0;
+  }
+  __syncthreads();  // the only workgroup-wide barrier
+  int bar_target = 0;
+  auto gsync = [&]() { group_barrier(&ctl.bar[group], bar_target); };
+
+  const int fstep = gridDim.x * kGroups;
+  int frame = blockIdx.x + gridDim.x * group;
   if (frame >= n) return;
   FrameHdr fh = load_hdr(offsets, headers, frame);
 
   int iter = 0;
   (void)iter;
-  for (; frame < n; frame += gridDim.x, ++iter) {
-    TSDF_STAMP(iter, 0);
+  for (; frame < n; frame += fstep, ++iter) {
+    TSDF_STAMP(kGroups * iter + group, 0);
     // the next frame's header/offsets are requested now, a whole frame ahead of their use
-    const int nframe = frame + gridDim.x;
+    const int nframe = frame + fstep;
     FrameHdr nfh = fh;
     if (nframe < n) nfh = load_hdr(offsets, headers, nframe);
 
@@ -763,6 +756,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     f.bh = f.b - f.t;
     f.depth = depth + fh.off0;
     float *out = out_tsdf ? out_tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
+    const bool want_vol = !aabb_only && out;
 
     int status = TSDF_FRAME_OK;
     Aabb ab;
@@ -775,17 +769,23 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     g.max_l = g.voxel_len = g.trunc = 0.f;
     g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
 
+    bool holds_stage = false;  // group-uniform
     if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != fh.off1 - fh.off0) {
-      status = TSDF_FRAME_BAD_HEADER;  // block-uniform
+      status = TSDF_FRAME_BAD_HEADER;  // group-uniform
     } else {
       float fin[kExt];
-      if (S > 0) {
-        combine_extents(out, S, fin);  // every wave reads the records before the staging barrier below
-      } else {
-        phase1_extents<kWaves>(f, cam, 0, f.bh, red, fin, iter);  // contains one __syncthreads()
-      }
+      // The group's first wave takes the stage lock on its way into the extents barrier, so the
+      // wait for the other group's phase 2 hides behind this group's own slowest wave.
+      auto sync_and_lock = [&]() {
+        if (want_vol && gwave == 0 && lane == 0) {
+          while (atomicCAS(&ctl.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+        }
+        gsync();
+      };
+      phase1_extents<kGWaves>(f, cam, 0, f.bh, red, fin, gwave, sync_and_lock, kGroups * iter + group);
+      holds_stage = want_vol;
       ab = aabb_from_extents(fin);
-      TSDF_STAMP(iter, 4);
+      TSDF_STAMP(kGroups * iter + group, 4);
       if (!ab.any) {
         status = TSDF_FRAME_DEGENERATE;
         ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
       }
     }
 
-    if (tid == 0) {
+    if (gtid == 0) {
       if (out_max_l) out_max_l[frame] = g.max_l;
       if (out_mid_p) {
         out_mid_p[3 * (int64_t)frame + 0] = g.mid[0];
@@ -822,10 +822,12 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
       }
     }
 
-    if (!aabb_only && out) {
+    bool ran_phase2 = false;
+    if (want_vol) {
       if (status != TSDF_FRAME_OK) {
-        zero_volume(out, R);
+        zero_volume(out, R, gtid);
       } else {
+        ran_phase2 = true;
         VoxK vk;
         vk.cx = cam.cx;
         vk.cy = cam.cy;
@@ -837,23 +839,26 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         vk.py0 = f.t + ab.r0;
         vk.dx = ab.c1 - ab.c0;
         vk.dy = ab.r1 - ab.r0;
+        const int sw = vk.dx + 1, sh = vk.dy + 1;
+        const bool staged = (int64_t)sw * sh <= kStageFloats;  // group-uniform
+        const float *__restrict__ srcp = f.depth + (int64_t)ab.r0 * f.bw + ab.c0;
 
-        // ---- per-frame tables (true divisions; one (x,z)/(y,z) pair per thread) ----
+        // ---- per-frame tables (true divisions; (x,z)/(y,z) pairs spread over the group) ----
         const double vl = (double)g.voxel_len;
         const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
-        if (tid < R) {
-          const double v_z = oz + (double)tid * vl;  // :28
+        TSDF_STAMP(kGroups * iter + group, 5);
+        if (gtid < R) {
+          const double v_z = oz + (double)gtid * vl;  // :28
           ZEntry ze;
-          ze.q = -cam.focal / v_z;                   // :30
+          ze.q = -cam.focal / v_z;                    // :30
           ze.vzs = v_z * vk.it;
-          ze.negthr = f32_round_up(-v_z);            // pd < -v_z  <=>  w_z > v_z  (:65)
+          ze.negthr = f32_round_up(-v_z);             // pd < -v_z  <=>  w_z > v_z  (:65)
           ze.pad = 0.f;
-          ztab[tid] = ze;
+          ztab[gtid] = ze;
         }
-        TSDF_STAMP(iter, 5);
-        const bool use_tab = R <= kTabR;  // block-uniform
+        const bool use_tab = R <= kTabR;  // uniform
         if (use_tab) {
-          for (int e = tid; e < R * R; e += kWG) {
+          for (int e = gtid; e < R * R; e += kGW) {
             const int z = e / R, i = e - z * R;
             const double q = -cam.focal / (oz + (double)z * vl);                              // :30
             const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
@@ -861,53 +866,52 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
             pytab[tab_index<LAYOUT>(i, z, R)] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);   // :32
           }
         }
+        TSDF_STAMP(kGroups * iter + group, 6);
 
-        TSDF_STAMP(iter, 6);
         // ---- stage the rectangle of valid pixels into LDS ----
-        const int sw = vk.dx + 1, sh = vk.dy + 1;
-        const bool staged = (int64_t)sw * sh <= kStageFloats;  // block-uniform
         if (staged) {
-          const float *__restrict__ srcp = f.depth + (int64_t)ab.r0 * f.bw + ab.c0;
-          for (int r0 = wave; r0 < sh; r0 += kWaves * 4) {
+          for (int r0 = gwave; r0 < sh; r0 += kGWaves * 4) {
             for (int cb = 0; cb < sw; cb += 256) {
               float v[4][4];
 #pragma unroll
               for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                  const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
+                  const int r = r0 + kGWaves * u, c = cb + lane + 64 * kk;
                   v[u][kk] = (r < sh && c < sw) ? srcp[(int64_t)r * f.bw + c] : 0.f;
                 }
 #pragma unroll
               for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                  const int r = r0 + kWaves * u, c = cb + lane + 64 * kk;
+                  const int r = r0 + kGWaves * u, c = cb + lane + 64 * kk;
                   if (r < sh && c < sw) stage[r * sw + c] = v[u][kk];
                 }
             }
           }
         }
-        TSDF_STAMP(iter, 7);
-        __syncthreads();
-        TSDF_STAMP(iter, 8);
+        TSDF_STAMP(kGroups * iter + group, 7);
+        gsync();
+        TSDF_STAMP(kGroups * iter + group, 8);
         if (staged) {
           vk.stride = sw;
           vk.base = 0;
-          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, stage, out);
+          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, stage, out, gtid);
         } else {
           vk.stride = f.bw;
           vk.base = ab.r0 * f.bw + ab.c0;
-          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, f.depth, out);
+          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, f.depth, out, gtid);
         }
       }
     }
-    TSDF_STAMP(iter, 9);
+    TSDF_STAMP(kGroups * iter + group, 9);
     fh = nfh;
-    // LDS reuse across frames: the stage/tables of the next frame may only be written once every wave
-    // has left this frame's phase 2.  In the fused form the next phase-1 barrier provides that for
-    // frames that ran phase 2; otherwise (no phase 1 here, or phase 2 skipped) close the frame here.
-    if (S > 0 || aabb_only || !out || status != TSDF_FRAME_OK) __syncthreads();
+    // Close the frame: every wave of the group has left the LDS it shares (stage/tables when phase 2
+    // ran, `red` otherwise) before the lock is handed over / the next frame rewrites `red`.
+    if (status != TSDF_FRAME_BAD_HEADER) gsync();
+    (void)ran_phase2;
+    if (holds_stage && gwave == 0 && lane == 0)
+      __hip_atomic_store(&ctl.lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
@@ -935,47 +939,14 @@ int check_device() {
   return TSDF_OK;
 }
 
-constexpr int kExtWaves = 4;    // kernel 1: 256-thread workgroups
-constexpr int kMaxBands = 16;   // extent records per frame (one 16-lane DPP row combines them)
-
-// row bands per frame for kernel 1: enough workgroups to fill the chip twice, 4 at batch >= 512
-int bands_for(int n) {
-  int s = (2 * 8 * num_cus() + n - 1) / n;  // ~8 workgroups of 256 threads per CU, two rounds
-  if (s < 4) s = 4;
-  if (s > kMaxBands) s = kMaxBands;
-  return s;
-}
-
 template <int RT, int LAYOUT>
 hipError_t launch(hipStream_t s, const float *d, const int64_t *o, const int32_t *h, int n, int R, CamK ck,
                   float *t, float *ml, float *mp, int32_t *st, float *ab, float *gr, float *orr,
                   int aabb_only) {
-  const int grid = n < num_cus() ? n : num_cus();  // persistent: one workgroup per CU
-  int S = 0;
-  const int64_t vol = (int64_t)3 * R * R * R;
-#ifdef TSDF_STAMPS
-  const bool two_launch = getenv("TSDF_DEBUG_FUSED") == nullptr;
-#else
-  const bool two_launch = true;
-#endif
-  if (two_launch && !aabb_only && t) {
-    // two launches: extents at high occupancy, then the LDS-staged voxelization
-    S = bands_for(n);
-    while ((int64_t)S * kRedStride > vol) S /= 2;  // the records live inside the frame's own volume
-    if (S >= 1) {
-      hipLaunchKernelGGL((tsdf_extents_kernel<kExtWaves>), dim3((unsigned)n * (unsigned)S), dim3(kExtWaves * 64),
-                         0, s, d, o, h, n, S, ck, t, vol);
-      hipError_t e1 = hipGetLastError();
-      if (e1 != hipSuccess) return e1;
-    } else {
-      S = 0;
-    }
-  }
-#ifdef TSDF_STAMPS
-  if (S > 0 && getenv("TSDF_DEBUG_SKIP_K2")) return hipGetLastError();  // diagnostic build only
-#endif
+  // persistent: one workgroup per CU; with fewer than kGroups frames per CU the later groups idle
+  const int grid = n < num_cus() ? n : num_cus();
   hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT>), dim3(grid), dim3(kWG), 0, s, d, o, h, n, R, ck, t, ml,
-                     mp, st, ab, gr, orr, aabb_only, S);
+                     mp, st, ab, gr, orr, aabb_only);
   return hipGetLastError();
 }
 

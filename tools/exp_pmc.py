@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""aabb-only and full launches for PMC collection (run under rocprofv3 --pmc ...)."""
+import importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
+synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+dev = torch.device("cuda:0")
+depth, off, hdr = synth.synth_batch(1024, "full", seed0=0)
+td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
+out = pkg.voxelize(td, to, th)
+mode = os.environ.get("PMC_MODE", "aabb")
+for _ in range(6):
+    if mode == "aabb":
+        pkg.aabb(td, to, th)
+    else:
+        pkg.voxelize(td, to, th, out=out)
+torch.cuda.synchronize()
