@@ -1,11 +1,22 @@
 """MI355X-native projective-TSDF voxelizer (drop-in for the reference's
-pre/tsdf_numba.py / pre/process.py voxelization path).
+pre/tsdf_numba.py / pre/tsdf_for.py / pre/process.py voxelization path).
 
 The compute path is the hand-written HIP library ``libtsdf_hip.so`` (csrc/tsdf_hip.hip)
 behind the C ABI of include/tsdf.h.  Nothing here falls back to a CPU implementation.
+
+Batched API (torch tensors on the GPU):  voxelize, voxelize_grid, aabb
+Reference-signature shims:               tsdf_numba.cal_tsdf_cuda, tsdf_for.tsdf_f / tsdf_cal,
+                                         process.DataProcess
+Host side:                               packing (MSRA .bin reader / batch packer), shard, synth
 """
 from . import _lib  # noqa: F401
 from ._lib import TsdfCam, TsdfError, default_cam  # noqa: F401
-from .voxelize import AabbBatch, TsdfBatch, aabb, voxelize  # noqa: F401
+from .voxelize import AabbBatch, TsdfBatch, aabb, voxelize, voxelize_grid  # noqa: F401
+from . import packing, shard, synth  # noqa: F401
+from .tsdf_numba import cal_tsdf_cuda  # noqa: F401
+from .tsdf_for import tsdf_cal, tsdf_f  # noqa: F401
+from .process import DataProcess  # noqa: F401
 
-__all__ = ["voxelize", "aabb", "TsdfBatch", "AabbBatch", "TsdfCam", "TsdfError", "default_cam"]
+__all__ = ["voxelize", "voxelize_grid", "aabb", "TsdfBatch", "AabbBatch", "TsdfCam", "TsdfError",
+           "default_cam", "cal_tsdf_cuda", "tsdf_f", "tsdf_cal", "DataProcess", "packing", "shard",
+           "synth"]

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
     float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
     float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
-    int aabb_only) {
+    int aabb_only, const float *__restrict__ grid_in) {
   __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
   __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
@@ -791,7 +791,16 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
       } else {
         g = glue(ab.mn, ab.mx, R, cam);
-        if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF)) {
+        if (grid_in) {
+          // caller-supplied placement (tsdf_cal's vox_ori, voxel_len, truncation arguments)
+          const float *gi = grid_in + 8 * (int64_t)frame;
+          g.ori[0] = gi[0];
+          g.ori[1] = gi[1];
+          g.ori[2] = gi[2];
+          g.voxel_len = gi[3];
+          g.trunc = gi[4];
+          if (!(g.trunc > 0.f) || !(g.trunc < TSDF_INF)) status = TSDF_FRAME_DEGENERATE;
+        } else if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF)) {
           status = TSDF_FRAME_DEGENERATE;
           g.max_l = g.voxel_len = g.trunc = 0.f;
         }
@@ -942,17 +951,17 @@ int check_device() {
 template <int RT, int LAYOUT>
 hipError_t launch(hipStream_t s, const float *d, const int64_t *o, const int32_t *h, int n, int R, CamK ck,
                   float *t, float *ml, float *mp, int32_t *st, float *ab, float *gr, float *orr,
-                  int aabb_only) {
+                  int aabb_only, const float *gin) {
   // persistent: one workgroup per CU; with fewer than kGroups frames per CU the later groups idle
   const int grid = n < num_cus() ? n : num_cus();
   hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT>), dim3(grid), dim3(kWG), 0, s, d, o, h, n, R, ck, t, ml,
-                     mp, st, ab, gr, orr, aabb_only);
+                     mp, st, ab, gr, orr, aabb_only, gin);
   return hipGetLastError();
 }
 
 int run(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
         const tsdf_cam *cam, int layout, void *hip_stream, float *t, float *ml, float *mp, int32_t *st,
-        float *ab, float *gr, float *orr, int aabb_only) {
+        float *ab, float *gr, float *orr, int aabb_only, const float *gin = nullptr) {
   if (n < 0 || !tsdf_resolution_supported(R)) return TSDF_ERR_INVALID_ARG;
   if (layout != TSDF_LAYOUT_CZYX && layout != TSDF_LAYOUT_CXYZ) return TSDF_ERR_INVALID_ARG;
   if (n == 0) return TSDF_OK;
@@ -973,13 +982,13 @@ int run(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipError_t e;
   if (layout == TSDF_LAYOUT_CZYX) {
-    if (R == 32) e = launch<32, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only);
-    else if (R == 64) e = launch<64, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only);
-    else e = launch<0, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only);
+    if (R == 32) e = launch<32, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
+    else if (R == 64) e = launch<64, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
+    else e = launch<0, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
   } else {
-    if (R == 32) e = launch<32, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only);
-    else if (R == 64) e = launch<64, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only);
-    else e = launch<0, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only);
+    if (R == 32) e = launch<32, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
+    else if (R == 64) e = launch<64, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
+    else e = launch<0, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
   }
   return e == hipSuccess ? TSDF_OK : TSDF_ERR_LAUNCH;
 }
@@ -1012,6 +1021,14 @@ int tsdf_voxelize_hip(const float *d_depth, const int64_t *d_offsets, const int3
   if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p)) return TSDF_ERR_INVALID_ARG;
   return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
              d_out_mid_p, d_out_status, nullptr, nullptr, nullptr, 0);
+}
+
+int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n,
+                           int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
+                           float *d_out_tsdf, int32_t *d_out_status) {
+  if (n > 0 && (!d_out_tsdf || !d_grid)) return TSDF_ERR_INVALID_ARG;
+  return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, nullptr, nullptr,
+             d_out_status, nullptr, nullptr, nullptr, 0, d_grid);
 }
 
 int tsdf_aabb_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,

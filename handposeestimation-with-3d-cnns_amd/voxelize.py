@@ -122,3 +122,38 @@ def aabb(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res:
                                  ab.data_ptr(), grid.data_ptr(), ori.data_ptr(), st.data_ptr())
         _lib.check(rc, "tsdf_aabb_hip")
     return AabbBatch(ab, grid, ori, st)
+
+
+def voxelize_grid(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, grid: torch.Tensor,
+                  res: int = 32, layout: str = "czyx", cam: Optional[_lib.TsdfCam] = None):
+    """Phase 2 with caller-supplied grid placement: the batched form of the reference's
+    ``tsdf_cal(data, vox_ori, voxel_len, truncation)`` (pre/tsdf_for.py:44-122).
+
+    grid  float32[n,8] on the GPU: vox_ori[3], voxel_len, trunc_dis, 3 pad words per frame.
+    Returns (tsdf float32[n,3,R,R,R], status int32[n]).
+    """
+    L = _lib.load()
+    if layout not in _lib.LAYOUTS:
+        raise ValueError("layout must be 'czyx' or 'cxyz'")
+    _dev_check("depth", depth, torch.float32)
+    dev = depth.device
+    _dev_check("offsets", offsets, torch.int64, dev)
+    _dev_check("headers", headers, torch.int32, dev)
+    _dev_check("grid", grid, torch.float32, dev)
+    n = headers.shape[0]
+    if offsets.numel() != n + 1 or tuple(grid.shape) != (n, 8):
+        raise ValueError("offsets must have n+1 entries and grid shape [n, 8]")
+    if not L.tsdf_resolution_supported(int(res)):
+        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
+    R = int(res)
+    tsdf = torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev)
+    st = torch.empty((n,), dtype=torch.int32, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.tsdf_voxelize_grid_hip(depth.data_ptr(), offsets.data_ptr(), headers.data_ptr(), n, R,
+                                          ctypes.byref(cam) if cam is not None else None,
+                                          _lib.LAYOUTS[layout], stream, grid.data_ptr(), tsdf.data_ptr(),
+                                          st.data_ptr())
+        _lib.check(rc, "tsdf_voxelize_grid_hip")
+    return tsdf, st

@@ -112,6 +112,20 @@ int tsdf_voxelize_hip(const float *d_depth, const int64_t *d_offsets, const int3
                       int32_t *d_out_status);
 
 /*
+ * Phase 2 with a caller-supplied grid placement — replaces tsdf_cal(data, vox_ori, voxel_len,
+ * truncation) (pre/tsdf_for.py:44-122 == DataProcess.tsdf_cal, pre/process.py:122-200) and
+ * tsdf_kernel launched on its own (pre/tsdf_numba.py:155-156).  This is what a drop-in for
+ * tsdf_f(data, point_cloud) needs: the reference derives the placement from the point cloud it is
+ * handed (pre/tsdf_for.py:9-16), not from the depth image.
+ *
+ *   d_grid  float32[n][8]  vox_ori[3], voxel_len, trunc_dis, then 3 pad words, per frame.
+ * Frames without a valid pixel, or with trunc_dis <= 0, give a zero volume (status 1).
+ */
+int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers,
+                           int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
+                           const float *d_grid, float *d_out_tsdf, int32_t *d_out_status);
+
+/*
  * Phase 1 + glue only: the per-frame axis-aligned bounding box of all valid
  * back-projected pixels and the grid placement derived from it.  Replaces
  * min_max_kernel + host glue (pre/tsdf_numba.py:75-116,135-147) on their own.

@@ -1,0 +1,140 @@
+"""CPU tier: host-side logic — MSRA .bin I/O and batch packing, sharding, the reference-signature
+shims' host halves, and "fails loudly without the HIP path"."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names
+
+
+def test_read_write_bin_round_trip(pkg, synth, tmp_path):
+    h, d = synth.synth_frame(3, "crop")
+    p = tmp_path / "000000_depth.bin"
+    pkg.packing.write_bin(str(p), h, d)
+    assert os.path.getsize(p) == 24 + 4 * d.size  # 6 x int32 + float32 payload (read_MSRA.py:158-162)
+    h2, d2 = pkg.packing.read_bin(str(p))
+    assert h2.dtype == np.int32 and d2.dtype == np.float32
+    np.testing.assert_array_equal(h, h2)
+    np.testing.assert_array_equal(d, d2)
+
+
+def test_read_bin_rejects_truncated_or_mismatched_files(pkg, synth, tmp_path):
+    h, d = synth.synth_frame(4, "crop")
+    p = tmp_path / "bad.bin"
+    pkg.packing.write_bin(str(p), h, d[:-5])
+    with pytest.raises(ValueError):
+        pkg.packing.read_bin(str(p))
+    with open(p, "wb") as f:
+        f.write(b"\x00" * 10)
+    with pytest.raises(ValueError):
+        pkg.packing.read_bin(str(p))
+
+
+def test_pack_frames_layout_and_slicing(pkg, synth):
+    frames = [synth.synth_frame(i, "crop") for i in range(7)]
+    pk = pkg.packing.pack_frames(frames)
+    assert len(pk) == 7 and pk.offsets[0] == 0 and pk.offsets[-1] == pk.depth.size
+    for i, (h, d) in enumerate(frames):
+        hh, dd = pk.frame(i)
+        np.testing.assert_array_equal(hh, h)
+        np.testing.assert_array_equal(dd, d)
+    sub = pk.slice(2, 5)
+    assert len(sub) == 3 and sub.offsets[0] == 0
+    np.testing.assert_array_equal(sub.frame(1)[1], frames[3][1])
+    # same three arrays as the synthetic generator's batch form
+    d2, o2, h2 = synth.synth_batch(7, "crop", 0)
+    np.testing.assert_array_equal(pk.depth, d2)
+    np.testing.assert_array_equal(pk.offsets, o2)
+    np.testing.assert_array_equal(pk.headers, h2)
+    empty = pkg.packing.pack_frames([])
+    assert len(empty) == 0 and empty.offsets.tolist() == [0]
+
+
+def test_pack_frames_rejects_inconsistent_frames(pkg, synth):
+    h, d = synth.synth_frame(1, "crop")
+    with pytest.raises(ValueError):
+        pkg.packing.pack_frames([(h, d[:-1])])
+    hb = h.copy()
+    hb[4] = hb[2]
+    with pytest.raises(ValueError):
+        pkg.packing.pack_frames([(hb, d)])
+
+
+def test_gesture_directory_reader(pkg, synth, tmp_path):
+    gdir = tmp_path / "P0" / "1"
+    gdir.mkdir(parents=True)
+    n = 5
+    gt = np.random.default_rng(0).normal(0, 50, (n, 63)).astype(np.float32)
+    with open(gdir / "joint.txt", "w") as f:
+        f.write(f"{n}\n")
+        for row in gt:
+            f.write(" ".join(f"{v:.6f}" for v in row) + "\n")
+    frames = [synth.synth_frame(20 + i, "crop") for i in range(n)]
+    for i, (h, d) in enumerate(frames):
+        pkg.packing.write_bin(str(gdir / ("%06d_depth.bin" % i)), h, d)
+    bin_num, gt2 = pkg.packing.read_joint(str(gdir))
+    assert bin_num == n
+    np.testing.assert_allclose(gt2, gt, atol=1e-5)
+    pk = pkg.packing.pack_bin_files(pkg.packing.gesture_bin_paths(str(gdir)))
+    assert len(pk) == n
+    np.testing.assert_array_equal(pk.frame(4)[1], frames[4][1])
+
+
+def test_shard_bounds_cover_and_balance(pkg):
+    sb = pkg.shard.shard_bounds
+    for n in (0, 1, 7, 8, 1024, 76531):
+        for w in (1, 2, 3, 8):
+            b = sb(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [e - s for s, e in b]
+            assert max(sizes) - min(sizes) <= 1
+    # weighted: balance by pixels
+    rng = np.random.default_rng(1)
+    wts = rng.integers(8000, 26000, 1000).astype(np.float64)
+    b = sb(1000, 8, wts)
+    loads = [wts[s:e].sum() for s, e in b]
+    assert b[0][0] == 0 and b[-1][1] == 1000
+    assert max(loads) / (wts.sum() / 8) < 1.03
+    with pytest.raises(ValueError):
+        sb(4, 0)
+    with pytest.raises(ValueError):
+        pkg.shard.shard_for_rank(4, 2, 2)
+
+
+@pytest.mark.parametrize("name", golden_names()[:3])
+def test_point_cloud_port_matches_reference_run(pkg, golden_dir, name):
+    """DataProcess.point_cloud / max_min_point (vectorised here) against the values the reference's own
+    loops produced (tools/make_goldens.py -> pc_min, pc_max, pc_n), bit for bit."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dp = pkg.DataProcess({"header": g["header"], "depth": g["depth"]}, np.zeros(63, np.float32))
+    pts = dp.point_cloud()
+    assert pts.shape == (int(g["pc_n"]), 3) and pts.dtype == np.float64
+    mx, mn = dp.max_min_point(pts)
+    np.testing.assert_array_equal(mx, g["pc_max"])
+    np.testing.assert_array_equal(mn, g["pc_min"])
+    rs = dp.set_length(pts)
+    assert rs.shape == (6000, 3)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_entry_points_fail_loudly_without_a_gpu(pkg, synth):
+    """No silent CPU fallback anywhere: every entry point raises when there is no HIP device."""
+    h, d = synth.synth_frame(0, "crop")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pkg.cal_tsdf_cuda({"header": h, "data": d})
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pkg.tsdf_f({"header": h, "depth": d}, np.array([[0, 0, -400.0], [50, 60, -300.0]]))
+    with pytest.raises(ValueError, match="no CPU path"):
+        pkg.voxelize(torch.from_numpy(d), torch.tensor([0, d.size]), torch.from_numpy(h[None]))
+    with pytest.raises(NotImplementedError):
+        pkg.DataProcess({"header": h, "depth": d}, np.zeros(63), aug=True).process()
+
+
+def test_missing_library_is_an_import_error(pkg, monkeypatch):
+    monkeypatch.setattr(pkg._lib, "_lib", None)
+    monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libtsdf_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        pkg._lib.load()

@@ -208,3 +208,58 @@ def test_full_size_properties(pkg, synth):
         ref = oracle.voxelize(depth[off[i]:off[i + 1]], o, hdr[i][None])
         assert np.abs(got[k] - ref["tsdf"][0]).max() <= TOL
         assert ref["max_l"][0] == float(out.max_l[i])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_grid_entry_against_reference_loop(pkg, golden_dir, name):
+    """tsdf_voxelize_grid_hip == tsdf_cal(data, vox_ori, voxel_len, truncation) as run by the reference
+    (golden G1): explicit placement, both layouts."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    d = dev()
+    depth = torch.from_numpy(g["depth"]).to(d)
+    off = torch.tensor([0, g["depth"].size], dtype=torch.int64, device=d)
+    hdr = torch.from_numpy(g["header"][None]).to(d)
+    grid = np.zeros((1, 8), np.float32)
+    grid[0, :3] = g["vox_ori"]
+    grid[0, 3] = g["voxel_len"]
+    grid[0, 4] = g["trunc"]
+    tg = torch.from_numpy(grid).to(d)
+    t0, st = pkg.voxelize_grid(depth, off, hdr, tg, layout="czyx")
+    t1, _ = pkg.voxelize_grid(depth, off, hdr, tg, layout="cxyz")
+    torch.cuda.synchronize()
+    assert int(st[0]) == 0
+    assert np.abs(t0[0].cpu().numpy() - g["loop64"]).max() <= TOL
+    assert np.abs(t1[0].cpu().numpy() - g["loop64"].transpose(0, 3, 2, 1)).max() <= TOL
+    assert np.abs(t0[0].cpu().numpy() - g["loop32"]).max() <= TOL
+
+
+def test_reference_signature_shims(pkg, golden_dir):
+    """cal_tsdf_cuda(s) / tsdf_f(data, point_cloud) / DataProcess.tsdf_cal with the reference's own
+    argument and return conventions."""
+    g = np.load(os.path.join(golden_dir, "crop_11.npz"))
+    header, depth = g["header"], g["depth"]
+    # numba entry: dict with 'data' (tsdf_numba.py:132) — and 'depth' as time_test.py passes it
+    for key in ("data", "depth"):
+        tsdf, max_l, mid_p = pkg.cal_tsdf_cuda({"header": header, key: depth})
+        assert tsdf.shape == (3, 32, 32, 32) and tsdf.dtype == np.float32
+        assert isinstance(max_l, np.float32) and max_l == g["max_l"]
+        assert mid_p.dtype == np.float32
+        np.testing.assert_array_equal(mid_p, g["mid_p"])
+        assert np.abs(tsdf - g["loop64"]).max() <= TOL
+    # loop entry: placement from the point cloud that is passed in, float64 [c,x,y,z] result
+    pc2 = np.stack([g["aabb_min"], g["aabb_max"]]).astype(np.float32)
+    tsdf_v, max_lenth, mid_point = pkg.tsdf_f({"header": header, "depth": depth}, pc2)
+    assert tsdf_v.shape == (3, 32, 32, 32) and tsdf_v.dtype == np.float64
+    assert max_lenth == g["max_l"]
+    np.testing.assert_array_equal(mid_point, g["mid_p"])
+    assert np.abs(tsdf_v - g["loop64"].transpose(0, 3, 2, 1)).max() <= TOL
+    # class entry
+    dp = pkg.DataProcess({"header": header, "depth": depth}, np.zeros(63, np.float32))
+    v = dp.tsdf_cal(g["vox_ori"], g["voxel_len"], g["trunc"])
+    assert np.abs(v - g["loop64"].transpose(0, 3, 2, 1)).max() <= TOL
+    np.random.seed(0)
+    res = dp.process()
+    assert len(res) == 4 and res[0].shape == (6000, 3) and res[1].shape == (3, 32, 32, 32)
+    # a frame the reference gives up on -> None (tsdf_numba.py:162-171)
+    empty = {"header": np.array([320, 240, 0, 0, 8, 8], np.int32), "data": np.zeros(64, np.float32)}
+    assert pkg.cal_tsdf_cuda(empty) is None
