@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of tools/make_profiles.sh and copy it into profiles/<tag>/.
+
+    python3 tools/collect_profiles.py gpurun_out/profiles_r01 summarize   # on the GPU box (writes summary.json there)
+    python3 tools/collect_profiles.py gpurun_out/profiles_r01 collect r01 # here: copy into profiles/r01 + pmc_traffic.json
+
+HBM traffic per launch (the `roofline.traffic` field of bench.py), following
+MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots":
+  * FETCH_SIZE and WRITE_SIZE are reported in KiB and come from separate passes;
+  * on gfx950 FETCH_SIZE reads exactly 1/2 of a wide (16 B/lane) coalesced streaming read -> x2 for the
+    phase-1 depth stream, whose reported size is isolated with the phase-1-only entry (tsdf_aabb_hip);
+  * the remaining reads are the 4 B/lane staging copy (uncalibrated width): they are priced at their
+    known byte count (sum over frames of the valid-pixel rectangle, computed from the same seeded
+    frames), and the reported number is kept next to it;
+  * WRITE_SIZE is exact for 16 B/lane streaming stores.
+"""
+import csv
+import glob
+import importlib
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "tsdf_fused_kernel<32, 0>"
+
+
+def counter_medians(d):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out[k] = {"median": float(np.median(v)), "n": len(v)}
+    return out
+
+
+def kernel_stats(d):
+    for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Name"]:
+                return {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                        "max_ns": float(r["MaxNs"]), "stddev_ns": float(r["StdDev"]), "file": os.path.basename(f)}
+    return None
+
+
+def staging_bytes():
+    sys.path.insert(0, ROOT)
+    synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+    tot = 0
+    for i in range(1024):
+        h, d = synth.synth_frame(i, "full")
+        img = np.abs(d.reshape(h[5] - h[3], h[4] - h[2])) >= 1
+        ys, xs = np.nonzero(img)
+        tot += int((ys.max() - ys.min() + 1) * (xs.max() - xs.min() + 1)) * 4
+    return tot
+
+
+def summarize(out):
+    s = {"kernel": KERNEL}
+    s["kernel_trace"] = kernel_stats(os.path.join(out, "trace"))
+    fetch = counter_medians(os.path.join(out, "pmc_fetch")).get("FETCH_SIZE")
+    write = counter_medians(os.path.join(out, "pmc_write")).get("WRITE_SIZE")
+    fetch_aabb = counter_medians(os.path.join(out, "pmc_fetch_aabb")).get("FETCH_SIZE")
+    s["pmc"] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "FETCH_SIZE_KiB_phase1_only": fetch_aabb}
+    s["sq"] = counter_medians(os.path.join(out, "pmc_sq"))
+    if fetch and write and fetch_aabb:
+        wide = fetch_aabb["median"] * 1024 * 2          # 16 B/lane stream: reported at 1/2
+        narrow_reported = (fetch["median"] - fetch_aabb["median"]) * 1024
+        stage = staging_bytes()
+        wr = write["median"] * 1024
+        s["traffic"] = {
+            "depth_stream_bytes": wide, "staging_bytes_known": stage, "staging_bytes_reported": narrow_reported,
+            "write_bytes": wr, "hbm_bytes_per_launch": wide + stage + wr,
+        }
+    try:
+        s["bench_unprofiled"] = json.loads(open(os.path.join(out, "bench_unprofiled.json")).read().strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        s["bench_unprofiled"] = str(e)
+    json.dump(s, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    print(json.dumps({k: s[k] for k in ("kernel_trace", "pmc")}, indent=1))
+    if "traffic" in s:
+        print(json.dumps(s["traffic"], indent=1))
+
+
+def collect(out, tag):
+    dst = os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    for sub, pat in (("trace", "*_kernel_stats.csv"), ("trace", "*_domain_stats.csv")):
+        for f in glob.glob(os.path.join(out, sub, "**", pat), recursive=True):
+            shutil.copy(f, os.path.join(dst, "bench_" + os.path.basename(f).split("_", 1)[1]))
+    for sub in ("pmc_fetch", "pmc_write", "pmc_fetch_aabb", "pmc_sq"):
+        for f in glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True):
+            rows = [r for r in csv.DictReader(open(f)) if "tsdf" in r["Kernel_Name"]]
+            keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                    "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+            with open(os.path.join(dst, sub + "_counters.csv"), "w", newline="") as g:
+                w = csv.DictWriter(g, fieldnames=keep)
+                w.writeheader()
+                for r in rows:
+                    w.writerow({k: r[k] for k in keep})
+    for f in ("summary.json", "bench_unprofiled.json"):
+        if os.path.exists(os.path.join(out, f)):
+            shutil.copy(os.path.join(out, f), os.path.join(dst, f))
+    s = json.load(open(os.path.join(out, "summary.json")))
+    if "traffic" in s:
+        t = dict(s["traffic"])
+        t["source"] = f"profiles/{tag}/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        json.dump(t, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print("copied into", dst)
+
+
+if __name__ == "__main__":
+    if sys.argv[2] == "summarize":
+        summarize(sys.argv[1])
+    else:
+        collect(sys.argv[1], sys.argv[3])
