@@ -16,7 +16,8 @@ depth = np.tile(depth, reps); hdr = np.tile(hdr, (reps, 1))
 off = np.concatenate([[0], np.cumsum(np.tile(np.diff(off), reps))]).astype(np.int64)
 td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
 print(os.environ.get("TSDF_HIP_LIB", "default lib"), kind)
-for n in (256, 512, 1024, 2048, 4096):
+NS = [int(v) for v in os.environ.get('PROF_NS', '256,512,1024,2048,4096').split(',')]
+for n in NS:
     o = to[: n + 1].contiguous(); h = th[:n].contiguous()
     out = pkg.voxelize(td, o, h)
     for _ in range(3): pkg.voxelize(td, o, h, out=out)
