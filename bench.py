@@ -107,8 +107,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL: barrier + max of elapsed only
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        # launched by torch.distributed.run: RCCL for the start/stop barrier + max of elapsed only
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
@@ -124,7 +126,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -193,7 +195,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

@@ -7,16 +7,18 @@ behind the C ABI of include/tsdf.h.  Nothing here falls back to a CPU implementa
 Batched API (torch tensors on the GPU):  voxelize, voxelize_grid, aabb
 Reference-signature shims:               tsdf_numba.cal_tsdf_cuda, tsdf_for.tsdf_f / tsdf_cal,
                                          process.DataProcess
-Host side:                               packing (MSRA .bin reader / batch packer), shard, synth
+Host side:                               packing (MSRA .bin reader / batch packer), shard, synth,
+                                         dataset (on-the-fly MSRADepthDataset / VoxelLoader, label normalisation)
 """
 from . import _lib  # noqa: F401
 from ._lib import TsdfCam, TsdfError, default_cam  # noqa: F401
 from .voxelize import AabbBatch, TsdfBatch, aabb, voxelize, voxelize_grid  # noqa: F401
-from . import packing, shard, synth  # noqa: F401
+from . import dataset, packing, shard, synth  # noqa: F401
+from .dataset import MSRADepthDataset, VoxelLoader, denormalize_joints, normalize_joints  # noqa: F401
 from .tsdf_numba import cal_tsdf_cuda  # noqa: F401
 from .tsdf_for import tsdf_cal, tsdf_f  # noqa: F401
 from .process import DataProcess  # noqa: F401
 
 __all__ = ["voxelize", "voxelize_grid", "aabb", "TsdfBatch", "AabbBatch", "TsdfCam", "TsdfError",
            "default_cam", "cal_tsdf_cuda", "tsdf_f", "tsdf_cal", "DataProcess", "packing", "shard",
-           "synth"]
+           "synth", "dataset", "MSRADepthDataset", "VoxelLoader", "normalize_joints", "denormalize_joints"]

@@ -138,3 +138,55 @@ def test_missing_library_is_an_import_error(pkg, monkeypatch):
     monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libtsdf_hip.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         pkg._lib.load()
+
+
+def _make_msra_tree(pkg, synth, root, n_sub=3, n_ges=2, n_frames=3):
+    rng = np.random.default_rng(5)
+    k = 0
+    for s in range(n_sub):
+        for g in range(n_ges):
+            gdir = root / f"P{s}" / f"{g + 1}"
+            gdir.mkdir(parents=True)
+            gt = rng.normal(0, 60, (n_frames, 63)).astype(np.float32)
+            with open(gdir / "joint.txt", "w") as f:
+                f.write(f"{n_frames}\n")
+                for row in gt:
+                    f.write(" ".join(f"{v:.6f}" for v in row) + "\n")
+            for i in range(n_frames):
+                h, d = synth.synth_frame(1000 + k, "crop")
+                pkg.packing.write_bin(str(gdir / ("%06d_depth.bin" % i)), h, d)
+                k += 1
+    return n_sub * n_ges * n_frames
+
+
+def test_on_the_fly_dataset_split_and_items(pkg, synth, tmp_path):
+    """Leave-one-subject-out split (3D_CNN/dataset.py:44-53) over raw .bin files; items are the raw
+    frame + label; collate gives the voxelizer's three input arrays."""
+    total = _make_msra_tree(pkg, synth, tmp_path)
+    subs = ["P0", "P1", "P2"]
+    tr = pkg.MSRADepthDataset(str(tmp_path), train=True, test_idx=1, subjects=subs)
+    te = pkg.MSRADepthDataset(str(tmp_path), train=False, test_idx=1, subjects=subs)
+    assert len(tr) == total * 2 // 3 and len(te) == total // 3
+    assert all("/P1/" not in p for p in tr.paths) and all("/P1/" in p for p in te.paths)
+    h, d, gt = tr[4]
+    assert h.shape == (6,) and d.dtype == np.float32 and gt.shape == (63,)
+    pk, g = pkg.dataset.collate_frames([tr[i] for i in range(5)])
+    assert len(pk) == 5 and g.shape == (5, 63)
+    np.testing.assert_array_equal(pk.frame(4)[1], d)
+    with pytest.raises(ValueError):
+        pkg.MSRADepthDataset(str(tmp_path), size="medium")
+
+
+def test_joint_normalisation_matches_reference_formula(pkg):
+    """(gt - mid_p) / max_l + 0.5 per joint (pre/joint_nor.py:8-18) and its inverse."""
+    rng = np.random.default_rng(2)
+    gt = rng.normal(0, 80, (6, 63)).astype(np.float32)
+    max_l = rng.uniform(150, 300, 6).astype(np.float32)
+    mid_p = rng.normal(0, 50, (6, 3)).astype(np.float32)
+    want = np.empty((6, 21, 3), np.float32)
+    for i in range(6):  # the reference's loop
+        want[i] = (gt[i].reshape(21, 3) - mid_p[i]) / max_l[i] + 0.5
+    got = pkg.normalize_joints(torch.from_numpy(gt), torch.from_numpy(max_l), torch.from_numpy(mid_p))
+    np.testing.assert_allclose(got.numpy().reshape(6, 21, 3), want, rtol=1e-6, atol=1e-6)
+    back = pkg.denormalize_joints(got, torch.from_numpy(max_l), torch.from_numpy(mid_p))
+    np.testing.assert_allclose(back.numpy(), gt, rtol=1e-5, atol=1e-3)

@@ -263,3 +263,40 @@ def test_reference_signature_shims(pkg, golden_dir):
     # a frame the reference gives up on -> None (tsdf_numba.py:162-171)
     empty = {"header": np.array([320, 240, 0, 0, 8, 8], np.int32), "data": np.zeros(64, np.float32)}
     assert pkg.cal_tsdf_cuda(empty) is None
+
+
+def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
+    """MSRA tree on disk -> VoxelLoader (worker thread, pinned upload on a side stream, HIP voxelizer)
+    -> the reference's (tsdf, gt, max_l, mid_p) tuple on the GPU, equal to the oracle on the same files."""
+    rng = np.random.default_rng(9)
+    frames, gts = [], []
+    for s in range(2):
+        for g in range(2):
+            gdir = tmp_path / f"P{s}" / f"{g + 1}"
+            gdir.mkdir(parents=True)
+            gt = rng.normal(0, 60, (4, 63)).astype(np.float32)
+            with open(gdir / "joint.txt", "w") as f:
+                f.write("4\n")
+                for row in gt:
+                    f.write(" ".join(f"{v:.6f}" for v in row) + "\n")
+            for i in range(4):
+                h, d = synth.synth_frame(2000 + len(frames), "crop")
+                pkg.packing.write_bin(str(gdir / ("%06d_depth.bin" % i)), h, d)
+                frames.append((h, d))
+    ds = pkg.MSRADepthDataset(str(tmp_path), train=True, test_idx=1, subjects=["P0", "P1"])
+    assert len(ds) == 8
+    loader = pkg.VoxelLoader(ds, batch_size=3, device=dev())
+    seen = 0
+    for tsdf, gt, max_l, mid_p in loader:
+        n = tsdf.shape[0]
+        assert tsdf.is_cuda and gt.shape == (n, 63)
+        pk = pkg.packing.pack_frames(frames[seen:seen + n])
+        ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32)
+        torch.cuda.synchronize()
+        assert np.abs(tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+        np.testing.assert_array_equal(max_l.cpu().numpy(), ref["max_l"])
+        np.testing.assert_array_equal(mid_p.cpu().numpy(), ref["mid_p"])
+        nj = pkg.normalize_joints(gt, max_l, mid_p)
+        assert nj.shape == gt.shape and bool(torch.isfinite(nj).all())
+        seen += n
+    assert seen == 8 and len(loader) == 3
