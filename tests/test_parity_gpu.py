@@ -300,3 +300,84 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
         assert nj.shape == gt.shape and bool(torch.isfinite(nj).all())
         seen += n
     assert seen == 8 and len(loader) == 3
+
+
+def test_large_rectangle_falls_back_to_global_gather(pkg):
+    """A valid-pixel rectangle over 32 Ki pixels does not fit the LDS stage: the gather then reads the
+    crop from global memory.  Same results."""
+    rng = np.random.default_rng(11)
+    img = np.zeros((480, 640), np.float32)
+    yy, xx = np.mgrid[0:480, 0:640]
+    blob = ((xx - 330) / 250.0) ** 2 + ((yy - 230) / 180.0) ** 2 < 1
+    img[blob] = (700 - 80 * np.sqrt(np.clip(1 - ((xx - 330) / 250.0) ** 2 - ((yy - 230) / 180.0) ** 2, 0, 1)))[blob]
+    img[blob] += rng.normal(0, 1, int(blob.sum())).astype(np.float32)
+    frames = [_frame(0, 0, 640, 480, img), _frame(40, 30, 611, 447, img)]
+    headers = np.stack([f[0] for f in frames])
+    offsets = np.zeros(3, np.int64)
+    offsets[1:] = np.cumsum([f[1].size for f in frames])
+    depth = np.concatenate([f[1] for f in frames])
+    for layout in ("czyx", "cxyz"):
+        got, _, _, _ = compare(pkg, depth, offsets, headers, 32, layout)
+        assert list(got["status"]) == [0, 0] and got["tsdf"].any()
+
+
+def test_resolution_128_and_tiny_batches(pkg, synth):
+    depth, off, hdr = synth.synth_batch(2, "crop", seed0=40)
+    compare(pkg, depth, off, hdr, 128, "czyx")
+    for n in (1, 3):
+        d, o, h = synth.synth_batch(n, "full", seed0=60)
+        compare(pkg, d, o, h, 32, "czyx")
+
+
+def test_many_small_crops_exercise_the_work_queue(pkg, synth):
+    """5,000 crops = ~20 frames per CU: everything beyond the first frame per group comes from the
+    dynamic queue; two back-to-back launches reuse queue slots."""
+    base = [synth.synth_frame(3000 + i, "crop") for i in range(250)]
+    frames = [base[i % 250] for i in range(5000)]
+    pk = pkg.packing.pack_frames(frames)
+    d = dev()
+    td, to, th = pk.to_torch(d)
+    out1 = pkg.voxelize(td, to, th)
+    out2 = pkg.voxelize(td, to, th)
+    torch.cuda.synchronize()
+    assert torch.equal(out1.tsdf, out2.tsdf) and bool((out1.status == 0).all())
+    # periodic input -> periodic output, and the first period matches the oracle
+    assert torch.equal(out1.tsdf[:250], out1.tsdf[4750:5000])
+    sub = pk.slice(0, 250)
+    ref = oracle.voxelize(sub.depth, sub.offsets, sub.headers, R=32, n_threads=8)
+    assert np.abs(out1.tsdf[:250].cpu().numpy() - ref["tsdf"]).max() <= TOL
+    np.testing.assert_array_equal(out1.max_l[:250].cpu().numpy(), ref["max_l"])
+
+
+def test_concurrent_streams_and_graph_replay(pkg, synth):
+    """Launches on two streams at once use different queue slots; a captured launch replays correctly."""
+    d = dev()
+    da, oa, ha = (torch.from_numpy(a).to(d) for a in synth.synth_batch(600, "crop", seed0=100))
+    db, ob, hb = (torch.from_numpy(a).to(d) for a in synth.synth_batch(600, "crop", seed0=900))
+    ref_a = pkg.voxelize(da, oa, ha)
+    ref_b = pkg.voxelize(db, ob, hb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(d), torch.cuda.Stream(d)
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            outs.append(("a", pkg.voxelize(da, oa, ha)))
+        with torch.cuda.stream(s2):
+            outs.append(("b", pkg.voxelize(db, ob, hb)))
+    torch.cuda.synchronize()
+    for tag, o in outs:
+        ref = ref_a if tag == "a" else ref_b
+        assert torch.equal(o.tsdf, ref.tsdf) and torch.equal(o.mid_p, ref.mid_p)
+    # hipGraph capture + replay (the call allocates nothing and does not synchronise)
+    out = pkg.voxelize(da, oa, ha)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream(d)
+    with torch.cuda.stream(cs):
+        with torch.cuda.graph(g, stream=cs):
+            pkg.voxelize(da, oa, ha, out=out)
+    for _ in range(3):
+        out.tsdf.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.tsdf, ref_a.tsdf)
