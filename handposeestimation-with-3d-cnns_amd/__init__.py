@@ -4,7 +4,7 @@ pre/tsdf_numba.py / pre/tsdf_for.py / pre/process.py voxelization path).
 The compute path is the hand-written HIP library ``libtsdf_hip.so`` (csrc/tsdf_hip.hip)
 behind the C ABI of include/tsdf.h.  Nothing here falls back to a CPU implementation.
 
-Batched API (torch tensors on the GPU):  voxelize, voxelize_grid, aabb
+Batched API (torch tensors on the GPU):  voxelize, voxelize_grid, voxelize_aug (fused 3-D augmentation), aabb
 Reference-signature shims:               tsdf_numba.cal_tsdf_cuda, tsdf_for.tsdf_f / tsdf_cal,
                                          process.DataProcess
 Host side:                               packing (MSRA .bin reader / batch packer), shard, synth,
@@ -12,13 +12,13 @@ Host side:                               packing (MSRA .bin reader / batch packe
 """
 from . import _lib  # noqa: F401
 from ._lib import TsdfCam, TsdfError, default_cam  # noqa: F401
-from .voxelize import AabbBatch, TsdfBatch, aabb, voxelize, voxelize_grid  # noqa: F401
-from . import dataset, packing, shard, synth  # noqa: F401
+from .voxelize import AabbBatch, TsdfBatch, aabb, voxelize, voxelize_aug, voxelize_grid  # noqa: F401
+from . import augment, dataset, packing, shard, synth  # noqa: F401
 from .dataset import MSRADepthDataset, VoxelLoader, denormalize_joints, normalize_joints  # noqa: F401
 from .tsdf_numba import cal_tsdf_cuda  # noqa: F401
 from .tsdf_for import tsdf_cal, tsdf_f  # noqa: F401
 from .process import DataProcess  # noqa: F401
 
-__all__ = ["voxelize", "voxelize_grid", "aabb", "TsdfBatch", "AabbBatch", "TsdfCam", "TsdfError",
+__all__ = ["voxelize", "voxelize_grid", "voxelize_aug", "augment", "aabb", "TsdfBatch", "AabbBatch", "TsdfCam", "TsdfError",
            "default_cam", "cal_tsdf_cuda", "tsdf_f", "tsdf_cal", "DataProcess", "packing", "shard",
            "synth", "dataset", "MSRADepthDataset", "VoxelLoader", "normalize_joints", "denormalize_joints"]

@@ -69,6 +69,9 @@ def load():
     L.tsdf_voxelize_grid_hip.restype = ctypes.c_int
     L.tsdf_voxelize_grid_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
                                          vp, vp, vp]
+    L.tsdf_voxelize_aug_hip.restype = ctypes.c_int
+    L.tsdf_voxelize_aug_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
+                                        vp, vp, vp, vp, vp]
     L.tsdf_aabb_hip.restype = ctypes.c_int
     L.tsdf_aabb_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, vp, vp, vp, vp, vp]
     _lib = L

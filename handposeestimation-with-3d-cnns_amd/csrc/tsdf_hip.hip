@@ -162,6 +162,18 @@ __device__ __forceinline__ double mul_then_add(double a, double b, double c) {
   return p + c;
 }
 
+// o = A p + b for one row {A_i0, A_i1, A_i2, b_i}: products and sums rounded separately, in this order
+// (the augmented form's arithmetic contract, oracle/tsdf_oracle.c::affine3).
+__device__ __forceinline__ double affine_row(const double *m, double px, double py, double pz) {
+#pragma clang fp contract(off)
+  double a = m[0] * px;
+  double b = m[1] * py;
+  double c = m[2] * pz;
+  double s = a + b;
+  s = s + c;
+  return s + m[3];
+}
+
 // fl64(d / F) without the hardware division sequence (~12 dependent float64 instructions):
 // with y = RN(1/F) computed by a true division on the host, q0 = RN(d*y) is within 1 ulp of d/F,
 // r = d - q0*F is exact in one fma, and RN(q0 + r*y) is the correctly rounded quotient (Markstein's
@@ -260,10 +272,12 @@ constexpr int kExt = 10;
 // ---- phase 1: extents of all valid back-projected pixels of rows [rbeg, rend) ----------------
 // NW waves cooperate (row = rbeg + wave + NW*i); the result is wave-uniform in every thread.
 // `wave` is the (scalar) index of this wave among the NW cooperating waves, `sync` their barrier.
-template <int NW, typename SYNC>
+// AUG: the extents are those of the affinely mapped cloud p' = A p + b (xf = 12 doubles), which needs
+// every valid pixel transformed (the monotone shortcut does not survive a rotation).
+template <int NW, bool AUG, typename SYNC>
 __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, int rbeg, int rend, float *red,
                                                float (&fin)[kExt], const int wave, SYNC sync,
-                                               int stamp_iter = 0) {
+                                               int stamp_iter = 0, const double *xf = nullptr) {
   (void)stamp_iter;
   constexpr int kWaves = NW;
   const int lane = threadIdx.x & 63;
@@ -332,7 +346,35 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
           if (part) a = fix_partial(a, p0);
         }
         // most 256-pixel segments hold no valid pixel at all: skip them wave-wide
-        if (row < rend && __any(vmaxabs4(a) >= k.eps)) {
+        if constexpr (AUG) {
+          if (row < rend && __any(vmaxabs4(a) >= k.eps)) {
+            const float d4[4] = {a.x, a.y, a.z, a.w};
+            const double ym = (double)(f.t + row) - k.cy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (__builtin_fabsf(d4[j]) >= k.eps) {  // pre/tsdf_numba.py:87
+                const int col = c0 + j;
+                const double q = div_by_focal((double)d4[j], k);            // :91
+                const double px = q * ((double)(f.l + col) - k.cx);         // :92
+                const double py = (-q) * ym;                                // :93
+                const double pz = -(double)d4[j];                           // :94
+                const float ax = (float)affine_row(xf + 0, px, py, pz);
+                const float ay = (float)affine_row(xf + 4, px, py, pz);
+                const float az = (float)affine_row(xf + 8, px, py, pz);
+                xmn = vmin(xmn, ax);
+                xmx = vmax(xmx, ax);
+                ymn = vmin(ymn, ay);
+                ymx = vmax(ymx, ay);
+                dmn = vmin(dmn, -az);  // stored negated: aabb_from_extents flips z back
+                dmx = vmax(dmx, -az);
+                cimn = vmin(cimn, (float)col);
+                cimx = vmax(cimx, (float)col);
+                rimn = vmin(rimn, (float)row);
+                rimx = vmax(rimx, (float)row);
+              }
+            }
+          }
+        } else if (row < rend && __any(vmaxabs4(a) >= k.eps)) {
           float rmin = TSDF_INF, rmax = -TSDF_INF;
           acc4(a, k.eps, cmin, cmax, rmin, rmax);
           const float wmin = wave_min(rmin), wmax = wave_max(rmax);
@@ -714,19 +756,93 @@ __device__ __forceinline__ void group_barrier(int *cnt, int &target) {
   asm volatile("" ::: "memory");
 }
 
+// Phase 2 of the augmented form (oracle/tsdf_oracle.c::tsdf_oracle_voxels_aug): the voxel centre v'
+// lives in the augmented frame, v = T^-1(v') is projected, the surface point w is mapped forward and the
+// distances are taken between v' and T(w).  No tables (the projection no longer factorises), one true
+// division per voxel for q = -F / v_z.
+template <int LAYOUT>
+__device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
+                                           const double *xf, const float *__restrict__ src,
+                                           float *__restrict__ out, const int tid) {
+  const double vl = (double)g.voxel_len;
+  const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
+  const double *fwd = xf, *inv = xf + 12;
+  const int R4 = R / 4;
+  const int G = R * R4;
+  const int64_t R3 = (int64_t)R * R * R;
+  int g0, gstep, s0, sstep;
+  if (G <= kGW && (kGW % G) == 0) {
+    g0 = tid % G;
+    gstep = G;
+    s0 = tid / G;
+    sstep = kGW / G;
+  } else {
+    g0 = tid;
+    gstep = kGW;
+    s0 = 0;
+    sstep = 1;
+  }
+  for (int gi = g0; gi < G; gi += gstep) {
+    const int f4i = (gi % R4) * 4;
+    const int y = gi / R4;
+    const double vpy = oy + (double)y * vl;
+    for (int sl = s0; sl < R; sl += sstep) {
+      float o0[4], o1[4], o2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = LAYOUT == 0 ? f4i + j : sl, z = LAYOUT == 0 ? sl : f4i + j;
+        const double vpx = ox + (double)x * vl, vpz = oz + (double)z * vl;
+        const double vx = affine_row(inv + 0, vpx, vpy, vpz);
+        const double vy = affine_row(inv + 4, vpx, vpy, vpz);
+        const double vz = affine_row(inv + 8, vpx, vpy, vpz);
+        const double q = -cam.focal / vz;                                        // :30
+        const int ex = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                // :31
+        const int ry = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);               // :32
+        const bool inb = (ex | ry) >= 0;                                         // :36
+        int idx = __mul24(ry, vk.stride) + ex + vk.base;
+        idx = inb ? idx : vk.base;
+        const float pd = src[idx];                                               // :38-39
+        const bool ok = inb & (__builtin_fabsf(pd) >= vk.eps);                   // :40
+        const double q2 = div_by_focal((double)pd, cam);                         // :43
+        const double wx = ((double)(ex + vk.px0) - cam.cx) * q2;                 // :44
+        const double wy = -((double)(ry + vk.py0) - cam.cy) * q2;                // :45
+        const double wz = -(double)pd;                                           // :46
+        const double ax = affine_row(fwd + 0, wx, wy, wz);
+        const double ay = affine_row(fwd + 4, wx, wy, wz);
+        const double az = affine_row(fwd + 8, wx, wy, wz);
+        const double tx = (vpx - ax) * vk.it, ty = (vpy - ay) * vk.it, tz = (vpz - az) * vk.it;  // :47-49
+        const double s2 = __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx));
+        const bool nearv = s2 <= 1.0;                                            // :54
+        const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
+        const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
+        const float m2 = vmin(__builtin_fabsf((float)tz), 1.0f);
+        const unsigned sg = az > vpz ? 0x80000000u : 0u;                         // w'_z > v'_z  :65
+        const unsigned keep = ok ? 0xffffffffu : 0u;
+        o0[j] = __uint_as_float((__float_as_uint(nearv ? m0 : 1.0f) | sg) & keep);
+        o1[j] = __uint_as_float((__float_as_uint(nearv ? m1 : 1.0f) | sg) & keep);
+        o2[j] = __uint_as_float((__float_as_uint(nearv ? m2 : 1.0f) | sg) & keep);
+      }
+      const int64_t e = ((int64_t)sl * R + y) * R + f4i;  // o[c][slow][y][fast]
+      store_vol4(out + e, f4{o0[0], o0[1], o0[2], o0[3]});
+      store_vol4(out + R3 + e, f4{o1[0], o1[1], o1[2], o1[3]});
+      store_vol4(out + 2 * R3 + e, f4{o2[0], o2[1], o2[2], o2[3]});
+    }
+  }
+}
+
 // Persistent kernel, one 1024-thread workgroup per CU.  Its two 512-thread groups each walk their
 // own frames  (frame = blockIdx.x + gridDim.x * (group + 2*i))  through
 //     stream rows -> extents -> glue        (no shared resource; the memory-bound part)
 //     [ tables -> stage -> phase 2 ]        (holds the LDS stage; the VALU/store-bound part)
 // and take turns on the single 128 KiB LDS stage, so one group's row streaming overlaps the other
 // group's voxel arithmetic and stores on the same CU.
-template <int RT, int LAYOUT>
+template <int RT, int LAYOUT, bool AUG>
 __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     const float *__restrict__ depth, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
     float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
     float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
-    int aabb_only, const float *__restrict__ grid_in, int qslot) {
+    int aabb_only, const float *__restrict__ grid_in, int qslot, const double *__restrict__ xforms) {
   __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
   __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
@@ -820,7 +936,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         }
         gsync();
       };
-      phase1_extents<kGWaves>(f, cam, 0, f.bh, red, fin, gwave, sync_and_lock, kGroups * iter + group);
+      phase1_extents<kGWaves, AUG>(f, cam, 0, f.bh, red, fin, gwave, sync_and_lock, kGroups * iter + group,
+                                   AUG ? xforms + 24 * (int64_t)frame : nullptr);
       holds_stage = want_vol;
       ab = aabb_from_extents(fin);
       TSDF_STAMP(kGroups * iter + group, 4);
@@ -904,7 +1021,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
           ze.pad = 0.f;
           ztab[gtid] = ze;
         }
-        const bool use_tab = R <= kTabR;  // uniform
+        const bool use_tab = !AUG && R <= kTabR;  // uniform
         if (use_tab) {
           for (int e = gtid; e < R * R; e += kGW) {
             const int z = e / R, i = e - z * R;
@@ -968,14 +1085,13 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         TSDF_STAMP(kGroups * iter + group, 7);
         gsync();
         TSDF_STAMP(kGroups * iter + group, 8);
-        if (staged) {
-          vk.stride = sw4;
-          vk.base = 0;
-          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, stage, out, gtid);
+        const float *gsrc = staged ? stage : f.depth;
+        vk.stride = staged ? sw4 : f.bw;
+        vk.base = staged ? 0 : ab.r0 * f.bw + ab.c0;
+        if constexpr (AUG) {
+          phase2_aug<LAYOUT>(g, cam, vk, R, xforms + 24 * (int64_t)frame, gsrc, out, gtid);
         } else {
-          vk.stride = f.bw;
-          vk.base = ab.r0 * f.bw + ab.c0;
-          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, f.depth, out, gtid);
+          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, gsrc, out, gtid);
         }
       }
     }
@@ -1022,22 +1138,44 @@ int check_device() {
   return TSDF_OK;
 }
 
-template <int RT, int LAYOUT>
-hipError_t launch(hipStream_t s, const float *d, const int64_t *o, const int32_t *h, int n, int R, CamK ck,
-                  float *t, float *ml, float *mp, int32_t *st, float *ab, float *gr, float *orr,
-                  int aabb_only, const float *gin) {
+// everything a launch needs, so that the dispatch over (R, layout, augmented) stays in one place
+struct LaunchArgs {
+  const float *depth;
+  const int64_t *offsets;
+  const int32_t *headers;
+  int n, R;
+  CamK ck;
+  float *tsdf, *max_l, *mid_p;
+  int32_t *status;
+  float *aabb, *grid, *ori;
+  int aabb_only;
+  const float *grid_in;
+  const double *xforms;
+};
+
+template <int RT, int LAYOUT, bool AUG>
+hipError_t launch(hipStream_t s, const LaunchArgs &a) {
   // persistent: one workgroup per CU; with fewer than kGroups frames per CU the later groups idle
-  const int grid = n < num_cus() ? n : num_cus();
+  const int grid = a.n < num_cus() ? a.n : num_cus();
   static std::atomic<unsigned int> launch_counter{0};
   const int qslot = (int)(launch_counter.fetch_add(1, std::memory_order_relaxed) % kQueueSlots);
-  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT>), dim3(grid), dim3(kWG), 0, s, d, o, h, n, R, ck, t, ml,
-                     mp, st, ab, gr, orr, aabb_only, gin, qslot);
+  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG>), dim3(grid), dim3(kWG), 0, s, a.depth, a.offsets,
+                     a.headers, a.n, a.R, a.ck, a.tsdf, a.max_l, a.mid_p, a.status, a.aabb, a.grid, a.ori,
+                     a.aabb_only, a.grid_in, qslot, a.xforms);
   return hipGetLastError();
+}
+
+template <int LAYOUT, bool AUG>
+hipError_t launch_r(hipStream_t s, const LaunchArgs &a) {
+  if (a.R == 32) return launch<32, LAYOUT, AUG>(s, a);
+  if (a.R == 64) return launch<64, LAYOUT, AUG>(s, a);
+  return launch<0, LAYOUT, AUG>(s, a);
 }
 
 int run(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
         const tsdf_cam *cam, int layout, void *hip_stream, float *t, float *ml, float *mp, int32_t *st,
-        float *ab, float *gr, float *orr, int aabb_only, const float *gin = nullptr) {
+        float *ab, float *gr, float *orr, int aabb_only, const float *gin = nullptr,
+        const double *xforms = nullptr) {
   if (n < 0 || !tsdf_resolution_supported(R)) return TSDF_ERR_INVALID_ARG;
   if (layout != TSDF_LAYOUT_CZYX && layout != TSDF_LAYOUT_CXYZ) return TSDF_ERR_INVALID_ARG;
   if (n == 0) return TSDF_OK;
@@ -1048,23 +1186,34 @@ int run(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers
     return TSDF_ERR_INVALID_ARG;
   int rc = check_device();
   if (rc != TSDF_OK) return rc;
-  CamK ck;
-  ck.focal = cam->focal;
-  ck.cx = cam->cx;
-  ck.cy = cam->cy;
-  ck.inv_focal = 1.0 / cam->focal;
-  ck.eps = cam->invalid_eps;
-  ck.trunc_vox = cam->trunc_voxels;
+  LaunchArgs a;
+  a.depth = d_depth;
+  a.offsets = d_offsets;
+  a.headers = d_headers;
+  a.n = n;
+  a.R = R;
+  a.ck.focal = cam->focal;
+  a.ck.cx = cam->cx;
+  a.ck.cy = cam->cy;
+  a.ck.inv_focal = 1.0 / cam->focal;
+  a.ck.eps = cam->invalid_eps;
+  a.ck.trunc_vox = cam->trunc_voxels;
+  a.tsdf = t;
+  a.max_l = ml;
+  a.mid_p = mp;
+  a.status = st;
+  a.aabb = ab;
+  a.grid = gr;
+  a.ori = orr;
+  a.aabb_only = aabb_only;
+  a.grid_in = gin;
+  a.xforms = xforms;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipError_t e;
-  if (layout == TSDF_LAYOUT_CZYX) {
-    if (R == 32) e = launch<32, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
-    else if (R == 64) e = launch<64, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
-    else e = launch<0, 0>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
+  if (xforms) {
+    e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, true>(s, a) : launch_r<1, true>(s, a);
   } else {
-    if (R == 32) e = launch<32, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
-    else if (R == 64) e = launch<64, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
-    else e = launch<0, 1>(s, d_depth, d_offsets, d_headers, n, R, ck, t, ml, mp, st, ab, gr, orr, aabb_only, gin);
+    e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, false>(s, a) : launch_r<1, false>(s, a);
   }
   return e == hipSuccess ? TSDF_OK : TSDF_ERR_LAUNCH;
 }
@@ -1105,6 +1254,15 @@ int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const
   if (n > 0 && (!d_out_tsdf || !d_grid)) return TSDF_ERR_INVALID_ARG;
   return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, nullptr, nullptr,
              d_out_status, nullptr, nullptr, nullptr, 0, d_grid);
+}
+
+int tsdf_voxelize_aug_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n,
+                          int R, const tsdf_cam *cam, int layout, void *hip_stream, const double *d_xforms,
+                          float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status) {
+  if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !d_xforms)) return TSDF_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(d_xforms) & 7) return TSDF_ERR_INVALID_ARG;
+  return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+             d_out_mid_p, d_out_status, nullptr, nullptr, nullptr, 0, nullptr, d_xforms);
 }
 
 int tsdf_aabb_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,

@@ -157,3 +157,47 @@ def voxelize_grid(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Ten
                                           st.data_ptr())
         _lib.check(rc, "tsdf_voxelize_grid_hip")
     return tsdf, st
+
+
+def voxelize_aug(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, xforms: torch.Tensor,
+                 res: int = 64, layout: str = "czyx", cam: Optional[_lib.TsdfCam] = None,
+                 out: Optional[TsdfBatch] = None) -> TsdfBatch:
+    """Voxelization with a per-frame 3-D affine augmentation fused into the kernel
+    (BASELINE.json configs[4]; see ``tsdf_voxelize_aug_hip`` in include/tsdf.h for the contract).
+
+    xforms  float64[n,24] on the GPU: forward map rows {A_i0,A_i1,A_i2,b_i} then the inverse map
+            (``augment.random_affines`` / ``augment.pack_affine`` build them).
+    Returns the same TsdfBatch as :func:`voxelize`; ``max_l`` / ``mid_p`` are in the mapped frame.
+    """
+    L = _lib.load()
+    if layout not in _lib.LAYOUTS:
+        raise ValueError("layout must be 'czyx' or 'cxyz'")
+    _dev_check("depth", depth, torch.float32)
+    dev = depth.device
+    _dev_check("offsets", offsets, torch.int64, dev)
+    _dev_check("headers", headers, torch.int32, dev)
+    _dev_check("xforms", xforms, torch.float64, dev)
+    n = headers.shape[0]
+    if offsets.numel() != n + 1 or tuple(xforms.shape) != (n, 24):
+        raise ValueError("offsets must have n+1 entries and xforms shape [n, 24]")
+    if not L.tsdf_resolution_supported(int(res)):
+        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
+    R = int(res)
+    if out is None:
+        out = TsdfBatch(
+            torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev),
+            torch.empty((n,), dtype=torch.float32, device=dev),
+            torch.empty((n, 3), dtype=torch.float32, device=dev),
+            torch.empty((n,), dtype=torch.int32, device=dev),
+        )
+    elif tuple(out.tsdf.shape) != (n, 3, R, R, R):
+        raise ValueError("out tensors have the wrong shape")
+    if n:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.tsdf_voxelize_aug_hip(depth.data_ptr(), offsets.data_ptr(), headers.data_ptr(), n, R,
+                                         ctypes.byref(cam) if cam is not None else None,
+                                         _lib.LAYOUTS[layout], stream, xforms.data_ptr(), out.tsdf.data_ptr(),
+                                         out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())
+        _lib.check(rc, "tsdf_voxelize_aug_hip")
+    return out

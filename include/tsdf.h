@@ -126,6 +126,26 @@ int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const
                            const float *d_grid, float *d_out_tsdf, int32_t *d_out_status);
 
 /*
+ * Augmented voxelization — BASELINE configs[4] (64^3 grid with 3-D augmentation fused into the TSDF
+ * kernel).  Replaces what DataProcess.data_aug + tsdf_f were meant to do (pre/process.py:19-24,202-261)
+ * but could not: data_aug raises AxisError on its own input, and where a variant of it runs
+ * (cut_version/pre/process.py:69-134,207) the augmented cloud only moves the grid while the TSDF still
+ * samples the un-augmented depth image.  This entry is therefore a RE-SPECIFICATION,
+ * parity unpinned; its arithmetic contract is oracle/tsdf_oracle.c::tsdf_oracle_voxels_aug:
+ *
+ *   d_xforms  float64[n][24]  per frame: the forward affine map T(p) = A p + b as three rows
+ *                             {A_i0, A_i1, A_i2, b_i}, then its inverse in the same form.
+ *   The AABB / grid placement is that of the mapped cloud T(p) over all valid pixels; a voxel centre v'
+ *   of that grid is mapped back (T^-1), projected and gathered as in tsdf_voxelize_hip, the surface
+ *   point is mapped forward and the truncated distances are taken between v' and T(w).
+ *   With the identity map the result equals tsdf_voxelize_hip.  max_l / mid_p are in the mapped frame.
+ */
+int tsdf_voxelize_aug_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers,
+                          int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
+                          const double *d_xforms, float *d_out_tsdf, float *d_out_max_l,
+                          float *d_out_mid_p, int32_t *d_out_status);
+
+/*
  * Phase 1 + glue only: the per-frame axis-aligned bounding box of all valid
  * back-projected pixels and the grid placement derived from it.  Replaces
  * min_max_kernel + host glue (pre/tsdf_numba.py:75-116,135-147) on their own.

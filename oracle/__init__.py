@@ -69,6 +69,10 @@ def lib():
         L.tsdf_oracle_voxelize.restype = ctypes.c_int
         L.tsdf_oracle_voxelize.argtypes = [fp, lp, ip, ctypes.c_int, ctypes.c_int, cp, ctypes.c_int,
                                            ctypes.c_int, fp, fp, fp, ip, fp, fp, fp]
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.tsdf_oracle_voxelize_aug.restype = ctypes.c_int
+        L.tsdf_oracle_voxelize_aug.argtypes = [fp, lp, ip, ctypes.c_int, ctypes.c_int, cp, ctypes.c_int,
+                                               ctypes.c_int, dp, fp, fp, fp, ip]
         _lib = L
     return _lib
 
@@ -138,3 +142,23 @@ def voxelize(depth, offsets, headers, R=32, layout=0, n_threads=1, want_tsdf=Tru
     if extras:
         res.update(aabb=ab, grid=grid, ori=ori)
     return res
+
+
+def voxelize_aug(depth, offsets, headers, xforms, R=32, layout=0, n_threads=1):
+    """Augmented form (re-specified, parity unpinned; see tsdf_oracle.c): xforms float64[n,24] =
+    forward affine rows {A_i0,A_i1,A_i2,b_i} then the inverse.  Returns dict(tsdf,max_l,mid_p,status)."""
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    headers = np.ascontiguousarray(headers, dtype=np.int32).reshape(-1, 6)
+    xforms = np.ascontiguousarray(xforms, dtype=np.float64).reshape(-1, 24)
+    n = headers.shape[0]
+    assert xforms.shape[0] == n
+    out = np.empty((n, 3, R, R, R), np.float32)
+    max_l = np.empty(n, np.float32)
+    mid_p = np.empty((n, 3), np.float32)
+    status = np.empty(n, np.int32)
+    lib().tsdf_oracle_voxelize_aug(
+        _p(depth, ctypes.c_float), _p(offsets, ctypes.c_int64), _p(headers, ctypes.c_int32), n, R, None,
+        layout, n_threads, _p(xforms, ctypes.c_double), _p(out, ctypes.c_float), _p(max_l, ctypes.c_float),
+        _p(mid_p, ctypes.c_float), _p(status, ctypes.c_int32))
+    return dict(tsdf=out, max_l=max_l, mid_p=mid_p, status=status)

@@ -248,3 +248,136 @@ int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32
   }
   return used;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Augmented form (BASELINE.json configs[4]).  The reference's data_aug
+ * (pre/process.py:202-261) raises AxisError on its own input and, where it runs (cut_version), only
+ * moves the grid while the TSDF still samples the un-augmented depth image (App. B#8-9), so there is
+ * NO reference output to match: this is a re-specification, parity unpinned, checked by construction
+ * (identity transform == plain path, bit for bit) and against the HIP kernel.
+ *
+ * xf = double[24] per frame: forward affine T(p) = A p + b as rows {A_i0, A_i1, A_i2, b_i} (12 values),
+ * then its inverse in the same form (12 values).  Every product/sum below is a separately rounded
+ * float64 operation, in the order written.
+ *   cloud:  p' = T(p) for the back-projected point p of every valid pixel (A.1, before the float32
+ *           rounding), then rounded to float32 for the AABB -> glue as in the plain path;
+ *   voxel:  centre v' lives in the augmented frame; v = T^-1(v') is projected (pre/tsdf_numba.py:30-32),
+ *           the surface point w of that pixel (:43-46) is mapped forward, w' = T(w), and the
+ *           truncated distances (:47-68) are taken between v' and w'.
+ */
+static void affine3(const double *m, const double *p, double *o) {
+  for (int i = 0; i < 3; ++i) o[i] = ((m[4 * i] * p[0] + m[4 * i + 1] * p[1]) + m[4 * i + 2] * p[2]) + m[4 * i + 3];
+}
+
+long tsdf_oracle_aabb_aug(const float *depth, const int32_t *header, const tsdf_cam *cam, const double *xf,
+                          float *min_p, float *max_p) {
+  if (!cam) cam = &k_default_cam;
+  const int l = header[2], t = header[3], r = header[4], b = header[5];
+  const int bw = r - l, bh = b - t;
+  long n_valid = 0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int row = 0; row < bh; ++row)
+    for (int col = 0; col < bw; ++col) {
+      const float d = depth[(long)row * bw + col];
+      if (fabsf(d) < cam->invalid_eps) continue;
+      const double q = (double)d / cam->focal;
+      const double p[3] = {q * ((double)(col + l) - cam->cx), -q * ((double)(row + t) - cam->cy), -(double)d};
+      double o[3];
+      affine3(xf, p, o);
+      for (int a = 0; a < 3; ++a) {
+        const float v = (float)o[a];
+        if (v < mn[a]) mn[a] = v;
+        if (v > mx[a]) mx[a] = v;
+      }
+      ++n_valid;
+    }
+  if (n_valid) {
+    memcpy(min_p, mn, sizeof mn);
+    memcpy(max_p, mx, sizeof mx);
+  }
+  return n_valid;
+}
+
+void tsdf_oracle_voxels_aug(const float *depth, const int32_t *header, const float *ori, float voxel_len,
+                            float trunc_dis, int R, const tsdf_cam *cam, int layout, const double *xf,
+                            float *out) {
+  if (!cam) cam = &k_default_cam;
+  const int l = header[2], t = header[3], r = header[4], b = header[5];
+  const int bw = r - l;
+  const size_t R3 = (size_t)R * R * R;
+  memset(out, 0, 3 * R3 * sizeof(float));
+  const double F = cam->focal;
+  const double *fwd = xf, *inv = xf + 12;
+  for (int z = 0; z < R; ++z)
+    for (int y = 0; y < R; ++y)
+      for (int x = 0; x < R; ++x) {
+        const double vp[3] = {(double)ori[0] + (double)x * (double)voxel_len,
+                              (double)ori[1] + (double)y * (double)voxel_len,
+                              (double)ori[2] + (double)z * (double)voxel_len};
+        double v[3];
+        affine3(inv, vp, v);
+        const double q = -F / v[2];
+        const int32_t pix_x = trunc_i32((v[0] * q) + cam->cx);
+        const int32_t pix_y = trunc_i32((-v[1] * q) + cam->cy);
+        if (pix_x < l || pix_x >= r || pix_y < t || pix_y >= b) continue;
+        const float pd = depth[(pix_y - t) * bw + pix_x - l];
+        if (fabsf(pd) < cam->invalid_eps) continue;
+        const double q2 = (double)pd / F;
+        const double w[3] = {((double)pix_x - cam->cx) * q2, -((double)pix_y - cam->cy) * q2, -(double)pd};
+        double wp[3], ts[3];
+        affine3(fwd, w, wp);
+        for (int a = 0; a < 3; ++a) ts[a] = fabs(vp[a] - wp[a]) / (double)trunc_dis;
+        const double dist = sqrt(ts[0] * ts[0] + ts[1] * ts[1] + ts[2] * ts[2]);
+        if (dist > 1.0) ts[0] = ts[1] = ts[2] = 1.0;
+        for (int a = 0; a < 3; ++a)
+          if (1.0 < ts[a]) ts[a] = 1.0;
+        if (wp[2] > vp[2])
+          for (int a = 0; a < 3; ++a) ts[a] = -ts[a];
+        const size_t vi = ((size_t)z * R + y) * R + x;
+        for (int a = 0; a < 3; ++a) {
+          const size_t o = layout == TSDF_LAYOUT_CXYZ ? (size_t)a * R3 + ((size_t)x * R + y) * R + z
+                                                      : (size_t)a * R3 + vi;
+          out[o] = (float)ts[a];
+        }
+      }
+}
+
+int tsdf_oracle_voxelize_aug(const float *depth, const int64_t *offsets, const int32_t *headers, int n, int R,
+                             const tsdf_cam *cam, int layout, int n_threads, const double *xforms,
+                             float *out_tsdf, float *out_max_l, float *out_mid_p, int32_t *out_status) {
+  if (!cam) cam = &k_default_cam;
+  if (n_threads <= 0) n_threads = 1;
+  const size_t vol = (size_t)3 * R * R * R;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#endif
+  for (int i = 0; i < n; ++i) {
+    const float *d = depth + offsets[i];
+    const int32_t *h = headers + 6 * (size_t)i;
+    const double *xf = xforms + 24 * (size_t)i;
+    const int bw = h[4] - h[2], bh = h[5] - h[3];
+    float grid[8] = {0}, ori[3] = {0}, mn[3] = {0}, mx[3] = {0};
+    int status = TSDF_FRAME_OK;
+    if (bw <= 0 || bh <= 0 || (int64_t)bw * bh != offsets[i + 1] - offsets[i]) {
+      status = TSDF_FRAME_BAD_HEADER;
+    } else if (tsdf_oracle_aabb_aug(d, h, cam, xf, mn, mx) == 0) {
+      status = TSDF_FRAME_DEGENERATE;
+    } else {
+      tsdf_oracle_glue(mn, mx, R, cam, grid, ori);
+      if (!(grid[3] > 0.0f) || !isfinite(grid[3])) {
+        status = TSDF_FRAME_DEGENERATE;
+        grid[3] = grid[4] = grid[5] = 0.0f;
+      }
+    }
+    if (out_tsdf) {
+      if (status == TSDF_FRAME_OK)
+        tsdf_oracle_voxels_aug(d, h, ori, grid[4], grid[5], R, cam, layout, xf, out_tsdf + vol * i);
+      else
+        memset(out_tsdf + vol * i, 0, vol * sizeof(float));
+    }
+    if (out_max_l) out_max_l[i] = grid[3];
+    if (out_mid_p) memcpy(out_mid_p + 3 * (size_t)i, grid, 3 * sizeof(float));
+    if (out_status) out_status[i] = status;
+  }
+  return n_threads;
+}

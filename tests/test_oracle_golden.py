@@ -105,3 +105,32 @@ def test_c_vs_numpy_restatement_many_frames(synth):
         out_n, pm_n = onp.voxels(d, h, ori, vl, tr)
         np.testing.assert_array_equal(pm_c, pm_n)
         np.testing.assert_array_equal(out_c, out_n)
+
+
+def test_augmented_oracle_identity_equals_plain_path(pkg, synth):
+    """Re-specified augmented form (parity unpinned): with the identity map it must equal the pinned
+    plain path bit for bit; the packed inverse must invert the forward map."""
+    d, o, h = synth.synth_batch(4, "crop", 31)
+    ident = pkg.augment.identity_affines(4)
+    a = oracle.voxelize_aug(d, o, h, ident, R=32)
+    b = oracle.voxelize(d, o, h, R=32)
+    np.testing.assert_array_equal(a["tsdf"], b["tsdf"])
+    np.testing.assert_array_equal(a["max_l"], b["max_l"])
+    np.testing.assert_array_equal(a["mid_p"], b["mid_p"])
+    xf, prm = pkg.augment.random_affines(b["mid_p"], rng=3)
+    assert xf.shape == (4, 24) and np.all((prm["stretch"] >= 2 / 3) & (prm["stretch"] <= 3 / 2))
+    assert np.all((prm["rot_xy"] >= -30) & (prm["rot_xy"] < 30))
+    pts = np.random.default_rng(0).normal(0, 100, (4, 21, 3))
+    fwd = pkg.augment.apply_affine(pts, xf)
+    inv = xf.reshape(4, 2, 3, 4)[:, 1]
+    back = np.einsum("nij,nkj->nki", inv[:, :, :3], fwd) + inv[:, None, :, 3]
+    np.testing.assert_allclose(back, pts, atol=1e-9)
+    # the centre is a fixed point of the map
+    np.testing.assert_allclose(pkg.augment.apply_affine(b["mid_p"][:, None, :].astype(np.float64), xf)[:, 0],
+                               b["mid_p"], atol=1e-9)
+    # a pure translation moves the grid and leaves the volume unchanged
+    t = np.array([12.5, -7.25, 30.0])
+    tr = pkg.augment.pack_affine(np.tile(np.eye(3), (4, 1, 1)), np.tile(t, (4, 1)))
+    c = oracle.voxelize_aug(d, o, h, tr, R=32)
+    np.testing.assert_allclose(c["mid_p"], b["mid_p"] + t, atol=1e-4)
+    assert np.abs(c["tsdf"] - b["tsdf"]).max() < 1e-3  # float32 re-rounding of the moved AABB only

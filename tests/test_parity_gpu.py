@@ -381,3 +381,40 @@ def test_concurrent_streams_and_graph_replay(pkg, synth):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out.tsdf, ref_a.tsdf)
+
+
+def test_augmented_entry(pkg, synth):
+    """tsdf_voxelize_aug_hip (BASELINE configs[4]; re-specified, parity unpinned -> checked against the
+    oracle's restatement of the same contract and by construction): identity map == plain path;
+    random reference-distribution augmentations at 32^3 and 64^3, both layouts."""
+    d = dev()
+    depth, off, hdr = synth.synth_batch(10, "crop", seed0=1200)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    plain = pkg.voxelize(td, to, th, res=32)
+    ident = torch.from_numpy(pkg.augment.identity_affines(10)).to(d)
+    a0 = pkg.voxelize_aug(td, to, th, ident, res=32)
+    torch.cuda.synchronize()
+    assert torch.equal(a0.max_l, plain.max_l) and torch.equal(a0.mid_p, plain.mid_p)
+    assert float((a0.tsdf - plain.tsdf).abs().max()) <= TOL
+    xf, _ = pkg.augment.random_affines(plain.mid_p.cpu().numpy(), rng=5)
+    txf = torch.from_numpy(xf).to(d)
+    for R in (32, 64):
+        for layout in ("czyx", "cxyz"):
+            got = pkg.voxelize_aug(td, to, th, txf, res=R, layout=layout)
+            torch.cuda.synchronize()
+            ref = oracle.voxelize_aug(depth, off, hdr, xf, R=R, layout=0 if layout == "czyx" else 1, n_threads=8)
+            np.testing.assert_array_equal(got.status.cpu().numpy(), ref["status"])
+            np.testing.assert_array_equal(got.max_l.cpu().numpy(), ref["max_l"])
+            np.testing.assert_array_equal(got.mid_p.cpu().numpy(), ref["mid_p"])
+            err = np.abs(got.tsdf.cpu().numpy() - ref["tsdf"])
+            assert err.max() <= TOL, (R, layout, err.max())
+    # full frames too (the 2-chunk row pass and the partial chunk)
+    depth, off, hdr = synth.synth_batch(3, "full", seed0=1300)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
+    xf, _ = pkg.augment.random_affines(mid, rng=6)
+    got = pkg.voxelize_aug(td, to, th, torch.from_numpy(xf).to(d), res=64)
+    torch.cuda.synchronize()
+    ref = oracle.voxelize_aug(depth, off, hdr, xf, R=64, n_threads=8)
+    np.testing.assert_array_equal(got.max_l.cpu().numpy(), ref["max_l"])
+    assert np.abs(got.tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
