@@ -48,7 +48,10 @@ constexpr int kWG = 1024;               // threads per workgroup (16 wave64; nee
 constexpr int kGroups = TSDF_GROUPS;    // half-workgroups: each walks its own frames, see the kernel
 constexpr int kGW = kWG / kGroups;      // threads per group
 constexpr int kGWaves = kGW / 64;       // waves per group
-constexpr int kRowUnroll = 4;           // rows in flight per wave in phase 1
+#ifndef TSDF_ROW_UNROLL
+#define TSDF_ROW_UNROLL 4
+#endif
+constexpr int kRowUnroll = TSDF_ROW_UNROLL;           // rows in flight per wave in phase 1
 constexpr int kMaxR = 128;
 constexpr int kStageFloats = 32 * 1024; // 128 KiB depth stage in LDS (>= 181 x 181 pixels)
 constexpr int kTabR = 32;               // projection tables for R <= kTabR (2 x 4 KiB)
