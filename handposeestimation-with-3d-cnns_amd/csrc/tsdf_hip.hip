@@ -9,30 +9,37 @@
 // unfused multiply-then-add for the pixel index, float32 store).
 //
 // Design (DESIGN.md has the numbers):
-//   * one 1024-thread workgroup (16 wave64) per frame, one workgroup per CU (it owns the LDS);
-//     the AABB and the grid placement never leave the chip;
-//   * phase 1 streams the crop once with 16-byte loads, lane <-> 4 consecutive columns,
-//     wave <-> rows.  It does NOT back-project every pixel (one float64 division each):
-//     f32(f64(d)/F * (x-cx)) is monotone in d for a fixed column x (and likewise per row),
-//     so the AABB is the extreme of the formula applied to each column's / row's (min,max)
-//     valid depth — 2(b_w+b_h) divisions per wave instead of b_w*b_h, bit-identical result.
-//     The same pass yields the pixel rectangle that holds every valid pixel;
+//   * one persistent launch; one 1024-thread workgroup (16 wave64) per CU, which owns the CU's LDS.
+//     Its two 512-thread halves ("groups") each process whole frames — the first one positional, the
+//     rest from an atomic work queue — and take turns on the single 128 KiB LDS stage, so one group's
+//     row streaming overlaps the other group's voxel arithmetic and stores.  Groups synchronise on LDS
+//     counters (s_barrier would span both).  The AABB and the grid placement never leave the chip;
+//   * phase 1 streams the crop once with 16-byte loads, lane <-> 4 consecutive columns, wave <-> rows,
+//     two register buffers in ping-pong behind counted vmcnt waits.  It does NOT back-project every
+//     pixel (one float64 division each): f32(f64(d)/F * (x-cx)) is monotone in d for a fixed column x
+//     (and likewise per row), so the AABB is the extreme of the formula applied to each column's /
+//     row's (min,max) valid depth — bit-identical result, 2(b_w+b_h) evaluations per wave instead of
+//     b_w*b_h; d/F uses Markstein's correction (exact quotient in 3 ops).  The same pass yields the pixel
+//     rectangle that holds every valid pixel;
 //   * staging: that rectangle (the only pixels phase 2 can ever use — everything outside it is
-//     rejected by pre/tsdf_numba.py:36 or :40) is copied into LDS (up to 144 KiB), so the
-//     per-voxel gather is an LDS read: no vector-memory latency, and stores never block loads;
-//     a rectangle that does not fit falls back to gathering from global memory (L2);
-//   * phase 2: each lane owns 4 consecutive voxels along the layout's fastest axis, so every
-//     wave store is 1 KiB contiguous (global_store_dwordx4); q = -F/v_z comes from a 1-per-z
-//     LDS table (true division), the per-voxel chain uses reciprocals (<= a few ulp64 from the
-//     divisions it replaces — 9 orders of magnitude inside the 1e-5 parity bound); a wave whose
-//     256 voxels are all rejected or farther than the truncation distance along z skips the
-//     x/y terms (the result is then (+-1,+-1,+-1) or 0 by pre/tsdf_numba.py:54-57).
-// HBM-bound streaming read + streaming write.  No MFMA (gather/scatter, not a contraction),
-// no CPU fallback, gfx950 only.
+//     rejected by pre/tsdf_numba.py:36 or :40) is copied into LDS by LDS-DMA (global_load_lds_dwordx4),
+//     so the per-voxel gather is an LDS read: no vector-memory latency, and stores never block loads;
+//     a rectangle over 32 Ki pixels falls back to gathering from global memory (L2);
+//   * phase 2: pix_x depends on (x,z) only and pix_y on (y,z) only -> both tabulated per frame in LDS
+//     (true division for q = -F/v_z, unfused multiply-add, v_cvt_i32_f64 truncation).  Each lane owns 4
+//     consecutive voxels along the layout's fastest axis, so every wave store is 1 KiB contiguous
+//     (global_store_dwordx4 nt: the volume is written once; non-temporal stores keep the streamed depth
+//     rows cached for the staging copy).  The per-voxel chain uses reciprocals (<= a few ulp64 from the
+//     divisions it replaces — 10 orders of magnitude inside the 1e-5 parity bound); a wave whose 256
+//     voxels are all rejected or farther than the truncation distance along z skips the x/y terms (the
+//     result is then (+-1,+-1,+-1) or 0 by pre/tsdf_numba.py:54-57);
+//   * the augmented form (template AUG) maps every valid pixel / voxel centre / surface point through a
+//     per-frame affine transform instead (tsdf_voxelize_aug_hip, re-specified: see include/tsdf.h).
+// HBM-bound streaming read + streaming write.  No MFMA (gather/scatter, not a contraction), no
+// inter-workgroup communication (XCD placement is irrelevant), no CPU fallback, gfx950 only.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <atomic>
 #include <type_traits>
