@@ -27,8 +27,6 @@ copy = torch.cuda.Stream(device=dev); comp = torch.cuda.current_stream(dev)
 maxpx = max(b[0].numel() for b in batches)
 dbuf = [(torch.empty(maxpx, dtype=torch.float32, device=dev), torch.empty(B + 1, dtype=torch.int64, device=dev),
          torch.empty((B, 6), dtype=torch.int32, device=dev)) for _ in range(2)]
-outs = [pkg.voxelize(*(t[:0] if False else t for t in (dbuf[k][0][:16], torch.tensor([0, 16], dtype=torch.int64, device=dev),
-        torch.tensor([[320, 240, 0, 0, 4, 4]], dtype=torch.int32, device=dev)))) for k in range(2)]
 def make_out(n):
     return pkg.TsdfBatch(torch.empty((n, 3, 32, 32, 32), dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
                          torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
