@@ -185,7 +185,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "tsdf_fused_kernel<32, 0>", "algorithmic_bytes_per_launch": abytes,
+                "kernel": "tsdf_fused_kernel<32, 0, false>", "algorithmic_bytes_per_launch": abytes,
                 "launch_ms_mean": round(mean_ms, 4), "launch_ms_median": round(float(np.median(kern_ms)), 4),
                 "launch_ms_min": round(float(kern_ms.min()), 4),
             },

@@ -12,7 +12,7 @@ for d in ['a','b','c']:
     for f in glob.glob("$OUT/"+d+"/**/*_counter_collection.csv",recursive=True):
         agg=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'tsdf_fused_kernel<32, 0' in r['Kernel_Name']:
+            if 'tsdf_fused_kernel<32, 0, false' in r['Kernel_Name']:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in sorted(agg.items()):
             v=sorted(v); print(k.ljust(34),'median=%.4g'%v[len(v)//2])
