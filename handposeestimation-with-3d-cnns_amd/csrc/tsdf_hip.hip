@@ -55,10 +55,6 @@ constexpr int kWG = 1024;               // threads per workgroup (16 wave64; nee
 constexpr int kGroups = TSDF_GROUPS;    // half-workgroups: each walks its own frames, see the kernel
 constexpr int kGW = kWG / kGroups;      // threads per group
 constexpr int kGWaves = kGW / 64;       // waves per group
-#ifndef TSDF_ROW_UNROLL
-#define TSDF_ROW_UNROLL 4
-#endif
-constexpr int kRowUnroll = TSDF_ROW_UNROLL;           // rows in flight per wave in phase 1
 constexpr int kMaxR = 128;
 constexpr int kStageFloats = 32 * 1024; // 128 KiB depth stage in LDS (>= 181 x 181 pixels)
 constexpr int kTabR = 32;               // projection tables for R <= kTabR (2 x 4 KiB)
@@ -110,15 +106,6 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-// max(|a|,|b|,|c|,|d|); NaN operands are ignored (IEEE maxNum), all-NaN gives NaN.
-__device__ __forceinline__ float vmaxabs4(f4 v) {
-  float r;
-  asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, %0, |%4|"
-      : "=&v"(r)
-      : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-  return r;
-}
-
 // ---- wave64 reductions: one DPP VALU op per step (s_nop 1 covers the VALU-write -> DPP-read hazard;
 // lanes whose DPP source is out of range are write-disabled and keep their value) ----------------
 #define TSDF_DPP_REDUCE(OP)                                                             \
@@ -205,57 +192,40 @@ __device__ __forceinline__ float backproject_y(float d, int y, const CamK &k) {
   return (float)((-q) * ((double)y - k.cy));
 }
 
-// Column plan of one lane for one 256-column chunk: which 4 columns it owns and how to load them
-// without ever touching memory outside the row (rows are packed back to back, and the last row
-// of the last frame ends the buffer).
-struct ColPlan {
-  int cl;      // clamped load column: min(c, bw-4)  -> the 16-byte load stays inside the row
-  int sh;      // c - cl in 0..3: the owned pixels are elements sh..3 of the loaded vector
-  bool own;    // c < bw: the lane owns at least one pixel of the row
+// P consecutive pixels of one lane, P in 1..8 (16-byte + 12/8/4-byte pieces, 4-byte aligned).
+template <int P>
+struct PixN {
+  float d[P];
 };
 
-__device__ __forceinline__ ColPlan make_plan(int c, int bw) {
-  ColPlan p;
-  p.cl = c < bw - 4 ? c : bw - 4;
-  if (p.cl < 0) p.cl = 0;
-  p.sh = c - p.cl;
-  p.own = c < bw;
-  return p;
-}
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
 
-// Fix-up for partial chunks (wave-uniform slow path): shift the owned pixels to elements 0.. and
-// blank (NaN = never valid) everything the lane does not own.
-__device__ __forceinline__ f4 fix_partial(f4 v, const ColPlan &p) {
-  const float nan = __builtin_nanf("");
-  const float e[4] = {v.x, v.y, v.z, v.w};
-  f4 r;
-  float o[4];
+template <int P>
+__device__ __forceinline__ PixN<P> load_pix(const float *__restrict__ p) {
+  PixN<P> r;
+  constexpr int Q = P / 4, T = P % 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float t = nan;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (j + s < 4) t = (p.sh == s) ? e[j + s] : t;
-    o[j] = p.own ? t : nan;
+  for (int q = 0; q < Q; ++q) {
+    const f4 v = *reinterpret_cast<const f4u *>(p + 4 * q);
+    r.d[4 * q] = v.x;
+    r.d[4 * q + 1] = v.y;
+    r.d[4 * q + 2] = v.z;
+    r.d[4 * q + 3] = v.w;
   }
-  r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+  if constexpr (T == 1) {
+    r.d[4 * Q] = p[4 * Q];
+  } else if constexpr (T == 2) {
+    const auto v = *reinterpret_cast<const f2u *>(p + 4 * Q);
+    r.d[4 * Q] = v.x;
+    r.d[4 * Q + 1] = v.y;
+  } else if constexpr (T == 3) {
+    const auto v = *reinterpret_cast<const f3u *>(p + 4 * Q);
+    r.d[4 * Q] = v.x;
+    r.d[4 * Q + 1] = v.y;
+    r.d[4 * Q + 2] = v.z;
+  }
   return r;
-}
-
-__device__ __forceinline__ void acc4(f4 v, float eps, float (&cmin)[4], float (&cmax)[4], float &rmin,
-                                     float &rmax) {
-  float lo[4], hi[4];
-  const float d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool ok = __builtin_fabsf(d[j]) >= eps;  // pre/tsdf_numba.py:87 (NaN -> invalid)
-    lo[j] = ok ? d[j] : TSDF_INF;
-    hi[j] = ok ? d[j] : -TSDF_INF;
-    cmin[j] = vmin(cmin[j], lo[j]);
-    cmax[j] = vmax(cmax[j], hi[j]);
-  }
-  rmin = vmin3(vmin3(rmin, lo[0], lo[1]), lo[2], lo[3]);
-  rmax = vmax3(vmax3(rmax, hi[0], hi[1]), hi[2], hi[3]);
 }
 
 struct Frame {
@@ -312,62 +282,70 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
     cnt = 0;
   };
 
-  // one pass over the rows per 256-column chunk (lane <-> 4 consecutive columns of the chunk)
-  auto chunk_pass = [&](int cbase, auto tiny_tag) {
-    constexpr bool tiny = decltype(tiny_tag)::value;  // bw < 4: no 16-byte load fits in a row
-    float cmin[4], cmax[4];
+  // One pass over the rows for the columns [cbase, cbase + 64*P): lane <-> P consecutive columns, so a
+  // row of up to 320 pixels is ONE visit with every lane busy (P = ceil(width / 64), at most 5).  Loads are
+  // unconditional vector loads in straight-line code (rows past the band are clamped and ignored), two
+  // register buffers in ping-pong: while one is reduced the other one's rows stream in behind a counted
+  // vmcnt.  A lane whose window crosses the row end reads into the next row (masked); only in the very
+  // last row of the frame would that leave the buffer, so that row alone takes guarded element loads.
+  auto row_pass = [&](int cbase, auto p_tag) {
+    constexpr int P = decltype(p_tag)::value;
+    constexpr int kU = P <= 4 ? 4 : 2;           // rows per register buffer
+    constexpr int kStep = kWaves * kU;
+    float cmin[P], cmax[P];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < P; ++j) {
       cmin[j] = TSDF_INF;
       cmax[j] = -TSDF_INF;
     }
-    const int c0 = cbase + 4 * lane;
-    const bool part = cbase + 256 > f.bw;  // the chunk is partial (wave-uniform)
-    const ColPlan p0 = make_plan(c0, f.bw);
+    const int c0 = cbase + P * lane;
+    bool mine[P];                                 // the lane owns column c0 + j
+#pragma unroll
+    for (int j = 0; j < P; ++j) mine[j] = c0 + j < f.bw;
+    const int cload = mine[0] ? c0 : f.bw - P;    // lanes past the row reload its last P pixels (all masked)
+    const bool ragged = (f.bw - cbase) % P != 0 && cbase + 64 * P >= f.bw;  // some lane straddles the row end
     const float nan = __builtin_nanf("");
 
-    // loads of one iteration: kRowUnroll rows, UNCONDITIONAL 16-byte loads in straight-line code (rows
-    // past the band are clamped to its last row and ignored later), so that the compiler can wait
-    // with a counted vmcnt for one buffer while the other buffer's loads stay in flight
-    auto load_rows = [&](int row0, f4 (&va)[kRowUnroll]) {
+    auto load_rows = [&](int row0, PixN<P> (&v)[kU]) {
 #pragma unroll
-      for (int u = 0; u < kRowUnroll; ++u) {
+      for (int u = 0; u < kU; ++u) {
         const int row = row0 + kWaves * u;
         const int rc = row < rend ? row : rend - 1;  // scalar
         const float *rp = f.depth + (int64_t)rc * f.bw;
-        if constexpr (!tiny) {
-          va[u] = *reinterpret_cast<const f4u *>(rp + p0.cl);
-        } else {  // bw in 1..3: element loads, only lane 0 owns pixels
-          va[u] = f4{nan, nan, nan, nan};
-          if (c0 < f.bw) va[u].x = rp[c0];
-          if (c0 + 1 < f.bw) va[u].y = rp[c0 + 1];
-          if (c0 + 2 < f.bw) va[u].z = rp[c0 + 2];
+        if (ragged && rc == f.bh - 1) {  // scalar, last row of the frame only: nothing may be read past it
+#pragma unroll
+          for (int j = 0; j < P; ++j) v[u].d[j] = mine[j] ? rp[c0 + j] : nan;
+        } else {
+          v[u] = load_pix<P>(rp + cload);
         }
       }
     };
 
-    auto reduce_rows = [&](int row0, const f4 (&va)[kRowUnroll]) {
-      if (cnt > 64 - kRowUnroll) flush_rows();  // wave-uniform (cnt is)
+    auto reduce_rows = [&](int row0, const PixN<P> (&v)[kU]) {
+      if (cnt > 64 - kU) flush_rows();  // wave-uniform (cnt is)
 #pragma unroll
-      for (int u = 0; u < kRowUnroll; ++u) {
+      for (int u = 0; u < kU; ++u) {
         const int row = row0 + kWaves * u;
-        f4 a = va[u];
-        if constexpr (!tiny) {
-          if (part) a = fix_partial(a, p0);
+        bool ok[P];
+        bool any_ok = false;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          ok[j] = (__builtin_fabsf(v[u].d[j]) >= k.eps) & mine[j];  // pre/tsdf_numba.py:87 (NaN -> invalid)
+          any_ok |= ok[j];
         }
-        // most 256-pixel segments hold no valid pixel at all: skip them wave-wide
-        if constexpr (AUG) {
-          if (row < rend && __any(vmaxabs4(a) >= k.eps)) {
-            const float d4[4] = {a.x, a.y, a.z, a.w};
+        // most row segments hold no valid pixel at all: skip them wave-wide
+        if (row < rend && __any(any_ok)) {
+          if constexpr (AUG) {
             const double ym = (double)(f.t + row) - k.cy;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (__builtin_fabsf(d4[j]) >= k.eps) {  // pre/tsdf_numba.py:87
+            for (int j = 0; j < P; ++j) {
+              if (ok[j]) {
                 const int col = c0 + j;
-                const double q = div_by_focal((double)d4[j], k);            // :91
+                const float dj = v[u].d[j];
+                const double q = div_by_focal((double)dj, k);               // :91
                 const double px = q * ((double)(f.l + col) - k.cx);         // :92
                 const double py = (-q) * ym;                                // :93
-                const double pz = -(double)d4[j];                           // :94
+                const double pz = -(double)dj;                              // :94
                 const float ax = (float)affine_row(xf + 0, px, py, pz);
                 const float ay = (float)affine_row(xf + 4, px, py, pz);
                 const float az = (float)affine_row(xf + 8, px, py, pz);
@@ -383,25 +361,30 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
                 rimx = vmax(rimx, (float)row);
               }
             }
+          } else {
+            float rmin = TSDF_INF, rmax = -TSDF_INF;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+              const float lo = ok[j] ? v[u].d[j] : TSDF_INF;
+              const float hi = ok[j] ? v[u].d[j] : -TSDF_INF;
+              cmin[j] = vmin(cmin[j], lo);
+              cmax[j] = vmax(cmax[j], hi);
+              rmin = vmin(rmin, lo);
+              rmax = vmax(rmax, hi);
+            }
+            const float wmin = wave_min(rmin), wmax = wave_max(rmax);
+            if (lane == cnt) {
+              s_rmin = wmin;
+              s_rmax = wmax;
+              s_row = row;
+            }
+            ++cnt;
           }
-        } else if (row < rend && __any(vmaxabs4(a) >= k.eps)) {
-          float rmin = TSDF_INF, rmax = -TSDF_INF;
-          acc4(a, k.eps, cmin, cmax, rmin, rmax);
-          const float wmin = wave_min(rmin), wmax = wave_max(rmax);
-          if (lane == cnt) {
-            s_rmin = wmin;
-            s_rmax = wmax;
-            s_row = row;
-          }
-          ++cnt;
         }
       }
     };
 
-    // two register buffers in ping-pong (no copies, so no wait is forced on the loads in flight):
-    // while one buffer is reduced the other one's kRowUnroll rows are streaming in
-    constexpr int kStep = kWaves * kRowUnroll;
-    f4 bufA[kRowUnroll], bufB[kRowUnroll];
+    PixN<P> bufA[kU], bufB[kU];
     load_rows(rbeg + wave, bufA);
     for (int row0 = rbeg + wave; row0 < rend; row0 += 2 * kStep) {
       load_rows(row0 + kStep, bufB);
@@ -409,29 +392,35 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
       load_rows(row0 + 2 * kStep, bufA);
       reduce_rows(row0 + kStep, bufB);
     }
-    // column extremes of this wave's rows -> x extent; depth extremes -> z extent
+    if constexpr (!AUG) {
+      // column extremes of this wave's rows -> x extent; depth extremes -> z extent
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (cmin[j] <= cmax[j]) {
-        const int col = c0 + j;
-        const int x = f.l + col;
-        const float a = backproject_x(cmin[j], x, k), b = backproject_x(cmax[j], x, k);
-        xmn = vmin3(xmn, a, b);
-        xmx = vmax3(xmx, a, b);
-        dmn = vmin(dmn, cmin[j]);
-        dmx = vmax(dmx, cmax[j]);
-        cimn = vmin(cimn, (float)col);
-        cimx = vmax(cimx, (float)col);
+      for (int j = 0; j < P; ++j) {
+        if (cmin[j] <= cmax[j]) {
+          const int col = c0 + j;
+          const int x = f.l + col;
+          const float a = backproject_x(cmin[j], x, k), b = backproject_x(cmax[j], x, k);
+          xmn = vmin3(xmn, a, b);
+          xmx = vmax3(xmx, a, b);
+          dmn = vmin(dmn, cmin[j]);
+          dmx = vmax(dmx, cmax[j]);
+          cimn = vmin(cimn, (float)col);
+          cimx = vmax(cimx, (float)col);
+        }
       }
     }
   };
-  // one pass over the rows per 256-column chunk (lane <-> 4 consecutive columns of the chunk)
-  if (rbeg >= rend) {
-    // empty band
-  } else if (f.bw >= 4) {
-    for (int cbase = 0; cbase < f.bw; cbase += 256) chunk_pass(cbase, std::false_type{});
-  } else {
-    chunk_pass(0, std::true_type{});
+  // P is capped at 5 (320 columns per pass, the MSRA sensor width): wider windows only cost registers
+  // (the whole kernel lives in 128 VGPRs) and would spill.
+  if (rbeg < rend) {
+    for (int cbase = 0; cbase < f.bw; cbase += 320) {
+      const int w = f.bw - cbase;  // columns left (scalar)
+      if (w <= 64) row_pass(cbase, std::integral_constant<int, 1>{});
+      else if (w <= 128) row_pass(cbase, std::integral_constant<int, 2>{});
+      else if (w <= 192) row_pass(cbase, std::integral_constant<int, 3>{});
+      else if (w <= 256) row_pass(cbase, std::integral_constant<int, 4>{});
+      else row_pass(cbase, std::integral_constant<int, 5>{});
+    }
   }
   TSDF_STAMP(stamp_iter, 1);
   flush_rows();
