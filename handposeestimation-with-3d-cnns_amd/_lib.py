@@ -64,16 +64,16 @@ def load():
     L.tsdf_default_cam.restype = None
     L.tsdf_default_cam.argtypes = [cam_p]
     L.tsdf_voxelize_hip.restype = ctypes.c_int
-    L.tsdf_voxelize_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
+    L.tsdf_voxelize_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
                                     vp, vp, vp, vp]
     L.tsdf_voxelize_grid_hip.restype = ctypes.c_int
-    L.tsdf_voxelize_grid_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
+    L.tsdf_voxelize_grid_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
                                          vp, vp, vp]
     L.tsdf_voxelize_aug_hip.restype = ctypes.c_int
-    L.tsdf_voxelize_aug_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
+    L.tsdf_voxelize_aug_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
                                         vp, vp, vp, vp, vp]
     L.tsdf_aabb_hip.restype = ctypes.c_int
-    L.tsdf_aabb_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, vp, vp, vp, vp, vp]
+    L.tsdf_aabb_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -841,7 +841,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
     float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
     float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
-    int aabb_only, const float *__restrict__ grid_in, int qslot, const double *__restrict__ xforms) {
+    int aabb_only, const float *__restrict__ grid_in, int qslot, const double *__restrict__ xforms,
+    int64_t depth_len) {
   __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
   __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
@@ -923,7 +924,9 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
 
     bool holds_stage = false;  // group-uniform
-    if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != fh.off1 - fh.off0) {
+    // a header that contradicts its payload, or a payload outside the depth buffer, is never read
+    if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != fh.off1 - fh.off0 || fh.off0 < 0 ||
+        fh.off1 > depth_len) {
       status = TSDF_FRAME_BAD_HEADER;  // group-uniform
     } else {
       float fin[kExt];
@@ -1150,6 +1153,7 @@ struct LaunchArgs {
   int aabb_only;
   const float *grid_in;
   const double *xforms;
+  int64_t depth_len;
 };
 
 template <int RT, int LAYOUT, bool AUG>
@@ -1160,7 +1164,7 @@ hipError_t launch(hipStream_t s, const LaunchArgs &a) {
   const int qslot = (int)(launch_counter.fetch_add(1, std::memory_order_relaxed) % kQueueSlots);
   hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG>), dim3(grid), dim3(kWG), 0, s, a.depth, a.offsets,
                      a.headers, a.n, a.R, a.ck, a.tsdf, a.max_l, a.mid_p, a.status, a.aabb, a.grid, a.ori,
-                     a.aabb_only, a.grid_in, qslot, a.xforms);
+                     a.aabb_only, a.grid_in, qslot, a.xforms, a.depth_len);
   return hipGetLastError();
 }
 
@@ -1171,14 +1175,14 @@ hipError_t launch_r(hipStream_t s, const LaunchArgs &a) {
   return launch<0, LAYOUT, AUG>(s, a);
 }
 
-int run(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
+int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
         const tsdf_cam *cam, int layout, void *hip_stream, float *t, float *ml, float *mp, int32_t *st,
         float *ab, float *gr, float *orr, int aabb_only, const float *gin = nullptr,
         const double *xforms = nullptr) {
   if (n < 0 || !tsdf_resolution_supported(R)) return TSDF_ERR_INVALID_ARG;
   if (layout != TSDF_LAYOUT_CZYX && layout != TSDF_LAYOUT_CXYZ) return TSDF_ERR_INVALID_ARG;
   if (n == 0) return TSDF_OK;
-  if (!d_depth || !d_offsets || !d_headers) return TSDF_ERR_INVALID_ARG;
+  if (!d_depth || !d_offsets || !d_headers || depth_len < 0) return TSDF_ERR_INVALID_ARG;
   if (!aabb_only && (!t || (reinterpret_cast<uintptr_t>(t) & 15))) return TSDF_ERR_INVALID_ARG;
   if (!cam) cam = &kDefaultCam;
   if (!(cam->focal > 0.0) || !(cam->invalid_eps > 0.0f) || !(cam->trunc_voxels > 0.0f))
@@ -1207,6 +1211,7 @@ int run(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers
   a.aabb_only = aabb_only;
   a.grid_in = gin;
   a.xforms = xforms;
+  a.depth_len = depth_len;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipError_t e;
   if (xforms) {
@@ -1239,35 +1244,35 @@ const char *tsdf_strerror(int status) {
 
 int tsdf_resolution_supported(int R) { return R >= 4 && R <= kMaxR && (R % 4) == 0; }
 
-int tsdf_voxelize_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n,
+int tsdf_voxelize_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                       int R, const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf,
                       float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status) {
   if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p)) return TSDF_ERR_INVALID_ARG;
-  return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
              d_out_mid_p, d_out_status, nullptr, nullptr, nullptr, 0);
 }
 
-int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n,
+int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                            int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
                            float *d_out_tsdf, int32_t *d_out_status) {
   if (n > 0 && (!d_out_tsdf || !d_grid)) return TSDF_ERR_INVALID_ARG;
-  return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, nullptr, nullptr,
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, nullptr, nullptr,
              d_out_status, nullptr, nullptr, nullptr, 0, d_grid);
 }
 
-int tsdf_voxelize_aug_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n,
+int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                           int R, const tsdf_cam *cam, int layout, void *hip_stream, const double *d_xforms,
                           float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status) {
   if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !d_xforms)) return TSDF_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(d_xforms) & 7) return TSDF_ERR_INVALID_ARG;
-  return run(d_depth, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
              d_out_mid_p, d_out_status, nullptr, nullptr, nullptr, 0, nullptr, d_xforms);
 }
 
-int tsdf_aabb_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
+int tsdf_aabb_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
                   const tsdf_cam *cam, void *hip_stream, float *d_out_aabb, float *d_out_grid,
                   float *d_out_ori, int32_t *d_out_status) {
-  return run(d_depth, d_offsets, d_headers, n, R, cam, TSDF_LAYOUT_CZYX, hip_stream, nullptr, nullptr,
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, TSDF_LAYOUT_CZYX, hip_stream, nullptr, nullptr,
              nullptr, d_out_status, d_out_aabb, d_out_grid, d_out_ori, 1);
 }
 

@@ -84,7 +84,7 @@ def voxelize(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, 
         return out
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = L.tsdf_voxelize_hip(depth.data_ptr(), offsets.data_ptr(), headers.data_ptr(), n, R,
+        rc = L.tsdf_voxelize_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                  ctypes.byref(cam) if cam is not None else None,
                                  _lib.LAYOUTS[layout], stream, out.tsdf.data_ptr(),
                                  out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())
@@ -117,7 +117,7 @@ def aabb(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res:
     if n:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.tsdf_aabb_hip(depth.data_ptr(), offsets.data_ptr(), headers.data_ptr(), n, int(res),
+            rc = L.tsdf_aabb_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, int(res),
                                  ctypes.byref(cam) if cam is not None else None, stream,
                                  ab.data_ptr(), grid.data_ptr(), ori.data_ptr(), st.data_ptr())
         _lib.check(rc, "tsdf_aabb_hip")
@@ -151,7 +151,7 @@ def voxelize_grid(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Ten
     if n:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.tsdf_voxelize_grid_hip(depth.data_ptr(), offsets.data_ptr(), headers.data_ptr(), n, R,
+            rc = L.tsdf_voxelize_grid_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                           ctypes.byref(cam) if cam is not None else None,
                                           _lib.LAYOUTS[layout], stream, grid.data_ptr(), tsdf.data_ptr(),
                                           st.data_ptr())
@@ -195,7 +195,7 @@ def voxelize_aug(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tens
     if n:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.tsdf_voxelize_aug_hip(depth.data_ptr(), offsets.data_ptr(), headers.data_ptr(), n, R,
+            rc = L.tsdf_voxelize_aug_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                          ctypes.byref(cam) if cam is not None else None,
                                          _lib.LAYOUTS[layout], stream, xforms.data_ptr(), out.tsdf.data_ptr(),
                                          out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 1
+#define TSDF_ABI_VERSION 2
 
 /* Output volume layouts.  Both hold float32[n][3][R][R][R]; channel c = x,y,z component. */
 enum tsdf_layout {
@@ -54,8 +54,9 @@ enum tsdf_frame_status {
   TSDF_FRAME_OK = 0,
   TSDF_FRAME_DEGENERATE = 1, /* no valid pixel, or AABB of zero extent: zero volume, max_l = 0.
                                 The reference prints and returns None here (tsdf_numba.py:162-171). */
-  TSDF_FRAME_BAD_HEADER = 2  /* right<=left, bottom<=top, or bbox area != offsets[i+1]-offsets[i]:
-                                zero volume, max_l = 0, mid_p = 0; depth is not read.               */
+  TSDF_FRAME_BAD_HEADER = 2  /* right<=left, bottom<=top, bbox area != offsets[i+1]-offsets[i], or the
+                                payload not inside [0, depth_len): zero volume, max_l = 0, mid_p = 0;
+                                depth is not read.                                                  */
 };
 
 /*
@@ -93,6 +94,8 @@ int tsdf_resolution_supported(int R);
  *                                   d_depth[offsets[i] .. offsets[i+1]), row-major
  *                                   over its bounding box, millimetres, 0 = no hand
  *                                   (the payload of an MSRA .bin, pre/read_MSRA.py:155-164).
+ *   depth_len  number of float32 elements in d_depth.  A frame whose [offsets[i], offsets[i+1]) does
+ *                                   not lie inside it is treated as TSDF_FRAME_BAD_HEADER and never read.
  *   d_offsets  int64[n+1]           element offsets into d_depth, non-decreasing.
  *   d_headers  int32[n][6]          W, H, left, top, right, bottom (the .bin header).
  *   n          number of frames (0 is allowed and is a no-op).
@@ -109,7 +112,7 @@ int tsdf_resolution_supported(int R);
  * float32 parameters, float64 intermediates, unfused multiply-add for the pixel
  * index, float32 store.  Results match that contract to <= 1e-5 absolute.
  */
-int tsdf_voxelize_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers,
+int tsdf_voxelize_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
                       int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
                       float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p,
                       int32_t *d_out_status);
@@ -124,7 +127,7 @@ int tsdf_voxelize_hip(const float *d_depth, const int64_t *d_offsets, const int3
  *   d_grid  float32[n][8]  vox_ori[3], voxel_len, trunc_dis, then 3 pad words, per frame.
  * Frames without a valid pixel, or with trunc_dis <= 0, give a zero volume (status 1).
  */
-int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers,
+int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
                            int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
                            const float *d_grid, float *d_out_tsdf, int32_t *d_out_status);
 
@@ -143,7 +146,7 @@ int tsdf_voxelize_grid_hip(const float *d_depth, const int64_t *d_offsets, const
  *   point is mapped forward and the truncated distances are taken between v' and T(w).
  *   With the identity map the result equals tsdf_voxelize_hip.  max_l / mid_p are in the mapped frame.
  */
-int tsdf_voxelize_aug_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers,
+int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
                           int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
                           const double *d_xforms, float *d_out_tsdf, float *d_out_max_l,
                           float *d_out_mid_p, int32_t *d_out_status);
@@ -158,7 +161,7 @@ int tsdf_voxelize_aug_hip(const float *d_depth, const int64_t *d_offsets, const 
  *   d_out_ori   float32[n][3]  vox_ori (:147)
  * Any of the three may be NULL.
  */
-int tsdf_aabb_hip(const float *d_depth, const int64_t *d_offsets, const int32_t *d_headers, int n,
+int tsdf_aabb_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                   int R, const tsdf_cam *cam, void *hip_stream, float *d_out_aabb,
                   float *d_out_grid, float *d_out_ori, int32_t *d_out_status);
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     L = pkg._lib.load()
     for name in declared_functions():
         assert hasattr(L, name), f"libtsdf_hip.so does not export {name}"
-    assert L.tsdf_version() == 1
+    assert L.tsdf_version() == 2
     assert b"no CPU fallback" in L.tsdf_strerror(-2)
 
 
@@ -47,14 +47,14 @@ def test_argument_validation_happens_before_device_work(pkg):
     L = pkg._lib.load()
     null = ctypes.c_void_p(0)
     # n == 0 is a no-op
-    assert L.tsdf_voxelize_hip(null, null, null, 0, 32, None, 0, null, null, null, null, null) == 0
+    assert L.tsdf_voxelize_hip(null, 0, null, null, 0, 32, None, 0, null, null, null, null, null) == 0
     # bad resolution / layout / null outputs -> TSDF_ERR_INVALID_ARG, never a crash
     one = ctypes.c_void_p(16)
-    assert L.tsdf_voxelize_hip(one, one, one, 1, 30, None, 0, null, one, one, one, null) == -1
-    assert L.tsdf_voxelize_hip(one, one, one, 1, 32, None, 7, null, one, one, one, null) == -1
-    assert L.tsdf_voxelize_hip(one, one, one, 1, 32, None, 0, null, null, one, one, null) == -1
-    assert L.tsdf_voxelize_hip(one, one, one, -1, 32, None, 0, null, one, one, one, null) == -1
-    assert L.tsdf_voxelize_grid_hip(one, one, one, 1, 32, None, 0, null, null, one, null) == -1
+    assert L.tsdf_voxelize_hip(one, 16, one, one, 1, 30, None, 0, null, one, one, one, null) == -1
+    assert L.tsdf_voxelize_hip(one, 16, one, one, 1, 32, None, 7, null, one, one, one, null) == -1
+    assert L.tsdf_voxelize_hip(one, 16, one, one, 1, 32, None, 0, null, null, one, one, null) == -1
+    assert L.tsdf_voxelize_hip(one, 16, one, one, -1, 32, None, 0, null, one, one, one, null) == -1
+    assert L.tsdf_voxelize_grid_hip(one, 16, one, one, 1, 32, None, 0, null, null, one, null) == -1
 
 
 def test_product_package_does_not_import_the_oracle():

@@ -418,3 +418,25 @@ def test_augmented_entry(pkg, synth):
     ref = oracle.voxelize_aug(depth, off, hdr, xf, R=64, n_threads=8)
     np.testing.assert_array_equal(got.max_l.cpu().numpy(), ref["max_l"])
     assert np.abs(got.tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
+def test_payload_outside_the_depth_buffer_is_never_read(pkg, synth):
+    """offsets that point past the depth buffer (or before it) mark the frame BAD_HEADER instead of reading
+    out of bounds; the other frames of the batch are unaffected."""
+    d = dev()
+    depth, off, hdr = synth.synth_batch(4, "crop", seed0=77)
+    good = run_hip(pkg, depth, off, hdr)
+    # drop the last frame's payload from the buffer but keep its offsets/header
+    cut = depth[: off[3]]
+    out = pkg.voxelize(torch.from_numpy(cut).to(d), torch.from_numpy(off).to(d), torch.from_numpy(hdr).to(d))
+    torch.cuda.synchronize()
+    assert out.status.cpu().tolist() == [0, 0, 0, 2]
+    assert not bool(out.tsdf[3].any()) and float(out.max_l[3]) == 0
+    np.testing.assert_array_equal(out.tsdf[:3].cpu().numpy(), good["tsdf"][:3])
+    # negative offset
+    off2 = off.copy()
+    off2[0] = -8
+    hdr2 = hdr.copy()
+    out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off2).to(d), torch.from_numpy(hdr2).to(d))
+    torch.cuda.synchronize()
+    assert int(out.status[0]) == 2 and out.status[1:].cpu().tolist() == [0, 0, 0]
