@@ -757,15 +757,20 @@ __device__ __forceinline__ void group_barrier(int *cnt, int &target) {
 
 // Phase 2 of the augmented form (oracle/tsdf_oracle.c::tsdf_oracle_voxels_aug): the voxel centre v'
 // lives in the augmented frame, v = T^-1(v') is projected, the surface point w is mapped forward and the
-// distances are taken between v' and T(w).  No tables (the projection no longer factorises), one true
-// division per voxel for q = -F / v_z.
+// distances are taken between v' and T(w).  The projection no longer factorises, so there are no pixel
+// tables and q = -F / v_z is one true division per voxel; what does factorise is the inverse map: its
+// three products per row, A_i0*v'_x, A_i1*v'_y, A_i2*v'_z, depend on one grid index each and are
+// tabulated per frame (atab, 9*R doubles), leaving ((a + b) + c) + d — the oracle's exact rounding order.
+// atab layout: [axis][index][row] = fl(inv[4*row + axis] * (ori_axis + index*voxel_len)).
 template <int LAYOUT>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
-                                           const double *xf, const float *__restrict__ src,
+                                           const double *xf, const double *atab, const float *__restrict__ src,
                                            float *__restrict__ out, const int tid) {
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
   const double *fwd = xf, *inv = xf + 12;
+  const double bi0 = inv[3], bi1 = inv[7], bi2 = inv[11];
+  const double *tabx = atab, *taby = atab + 3 * R, *tabz = atab + 6 * R;
   const int R4 = R / 4;
   const int G = R * R4;
   const int64_t R3 = (int64_t)R * R * R;
@@ -785,41 +790,71 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
     const double vpy = oy + (double)y * vl;
+    const double ty0 = taby[3 * y], ty1 = taby[3 * y + 1], ty2 = taby[3 * y + 2];
     for (int sl = s0; sl < R; sl += sstep) {
-      float o0[4], o1[4], o2[4];
+      // ---- project the 4 voxels and gather their depths ----
+      int ex[4], ry[4];
+      float pd[4];
+      bool ok[4];
+      double vpx[4], vpz[4], az[4], tz[4], q2[4];
+      bool any_near = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int x = LAYOUT == 0 ? f4i + j : sl, z = LAYOUT == 0 ? sl : f4i + j;
-        const double vpx = ox + (double)x * vl, vpz = oz + (double)z * vl;
-        const double vx = affine_row(inv + 0, vpx, vpy, vpz);
-        const double vy = affine_row(inv + 4, vpx, vpy, vpz);
-        const double vz = affine_row(inv + 8, vpx, vpy, vpz);
+        vpx[j] = ox + (double)x * vl;
+        vpz[j] = oz + (double)z * vl;
+        const double *tx = tabx + 3 * x, *tzp = tabz + 3 * z;
+        const double vx = ((tx[0] + ty0) + tzp[0]) + bi0;                        // v = T^-1(v')
+        const double vy = ((tx[1] + ty1) + tzp[1]) + bi1;
+        const double vz = ((tx[2] + ty2) + tzp[2]) + bi2;
         const double q = -cam.focal / vz;                                        // :30
-        const int ex = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                // :31
-        const int ry = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);               // :32
-        const bool inb = (ex | ry) >= 0;                                         // :36
-        int idx = __mul24(ry, vk.stride) + ex + vk.base;
+        ex[j] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                       // :31
+        ry[j] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);                      // :32
+        const bool inb = (ex[j] | ry[j]) >= 0;                                   // :36
+        int idx = __mul24(ry[j], vk.stride) + ex[j] + vk.base;
         idx = inb ? idx : vk.base;
-        const float pd = src[idx];                                               // :38-39
-        const bool ok = inb & (__builtin_fabsf(pd) >= vk.eps);                   // :40
-        const double q2 = div_by_focal((double)pd, cam);                         // :43
-        const double wx = ((double)(ex + vk.px0) - cam.cx) * q2;                 // :44
-        const double wy = -((double)(ry + vk.py0) - cam.cy) * q2;                // :45
-        const double wz = -(double)pd;                                           // :46
-        const double ax = affine_row(fwd + 0, wx, wy, wz);
-        const double ay = affine_row(fwd + 4, wx, wy, wz);
-        const double az = affine_row(fwd + 8, wx, wy, wz);
-        const double tx = (vpx - ax) * vk.it, ty = (vpy - ay) * vk.it, tz = (vpz - az) * vk.it;  // :47-49
-        const double s2 = __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx));
-        const bool nearv = s2 <= 1.0;                                            // :54
-        const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
-        const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
-        const float m2 = vmin(__builtin_fabsf((float)tz), 1.0f);
-        const unsigned sg = az > vpz ? 0x80000000u : 0u;                         // w'_z > v'_z  :65
-        const unsigned keep = ok ? 0xffffffffu : 0u;
-        o0[j] = __uint_as_float((__float_as_uint(nearv ? m0 : 1.0f) | sg) & keep);
-        o1[j] = __uint_as_float((__float_as_uint(nearv ? m1 : 1.0f) | sg) & keep);
-        o2[j] = __uint_as_float((__float_as_uint(nearv ? m2 : 1.0f) | sg) & keep);
+        pd[j] = src[idx];                                                        // :38-39
+        ok[j] = inb & (__builtin_fabsf(pd[j]) >= vk.eps);                        // :40
+      }
+      // ---- z component first: a wave whose voxels are all rejected or beyond the truncation distance
+      // along z' alone needs nothing else (dist >= |tz| > 1 -> (1,1,1)) ----
+      double wx[4], wy[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q2[j] = div_by_focal((double)pd[j], cam);                                // :43
+        wx[j] = ((double)(ex[j] + vk.px0) - cam.cx) * q2[j];                     // :44
+        wy[j] = -((double)(ry[j] + vk.py0) - cam.cy) * q2[j];                    // :45
+        az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
+        tz[j] = (vpz[j] - az[j]) * vk.it;                                        // :49
+        any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
+      }
+      float o0[4], o1[4], o2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o0[j] = o1[j] = o2[j] = 1.0f;
+      if (__any(any_near)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double wz = -(double)pd[j];
+          const double ax = affine_row(fwd + 0, wx[j], wy[j], wz);
+          const double ay = affine_row(fwd + 4, wx[j], wy[j], wz);
+          const double tx = (vpx[j] - ax) * vk.it, ty = (vpy - ay) * vk.it;      // :47-48
+          const double s2 = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));
+          const bool nearv = s2 <= 1.0;                                          // :54
+          const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
+          const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
+          const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
+          o0[j] = nearv ? m0 : 1.0f;
+          o1[j] = nearv ? m1 : 1.0f;
+          o2[j] = nearv ? m2 : 1.0f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned keep = ok[j] ? 0xffffffffu : 0u;
+        const unsigned sg = (az[j] > vpz[j] ? 0x80000000u : 0u) & keep;         // w'_z > v'_z  :65
+        o0[j] = __uint_as_float((__float_as_uint(o0[j]) & keep) | sg);
+        o1[j] = __uint_as_float((__float_as_uint(o1[j]) & keep) | sg);
+        o2[j] = __uint_as_float((__float_as_uint(o2[j]) & keep) | sg);
       }
       const int64_t e = ((int64_t)sl * R + y) * R + f4i;  // o[c][slow][y][fast]
       store_vol4(out + e, f4{o0[0], o0[1], o0[2], o0[3]});
@@ -847,6 +882,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
   __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
   __shared__ __attribute__((aligned(16))) ZEntry ztab[kMaxR];
+  __shared__ __attribute__((aligned(16))) double atab[AUG ? 9 * kMaxR : 1];  // inverse-map products (AUG)
   __shared__ float red_all[kGroups][kGWaves * kRedStride];
   __shared__ GroupCtl ctl;
 
@@ -1023,6 +1059,15 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
           ze.pad = 0.f;
           ztab[gtid] = ze;
         }
+        if constexpr (AUG) {
+          // products of the inverse map, one per (axis, index, row): see phase2_aug
+          const double *inv = xforms + 24 * (int64_t)frame + 12;
+          for (int e = gtid; e < 9 * R; e += kGW) {
+            const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
+            const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
+            atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
+          }
+        }
         const bool use_tab = !AUG && R <= kTabR;  // uniform
         if (use_tab) {
           for (int e = gtid; e < R * R; e += kGW) {
@@ -1091,7 +1136,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         vk.stride = staged ? sw4 : f.bw;
         vk.base = staged ? 0 : ab.r0 * f.bw + ab.c0;
         if constexpr (AUG) {
-          phase2_aug<LAYOUT>(g, cam, vk, R, xforms + 24 * (int64_t)frame, gsrc, out, gtid);
+          phase2_aug<LAYOUT>(g, cam, vk, R, xforms + 24 * (int64_t)frame, atab, gsrc, out, gtid);
         } else {
           phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, gsrc, out, gtid);
         }
