@@ -290,7 +290,7 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
   // last row of the frame would that leave the buffer, so that row alone takes guarded element loads.
   auto row_pass = [&](int cbase, auto p_tag) {
     constexpr int P = decltype(p_tag)::value;
-    constexpr int kU = P <= 4 ? 4 : 2;           // rows per register buffer
+    constexpr int kU = P <= 4 ? 4 : 3;           // rows per register buffer (bytes in flight vs VGPRs)
     constexpr int kStep = kWaves * kU;
     float cmin[P], cmax[P];
 #pragma unroll
