@@ -81,8 +81,14 @@ __device__ unsigned long long g_stamps[kStampBlocks * kStampFrames * kStampSlots
       g_stamps[(blockIdx.x * kStampFrames + (iter)) * kStampSlots + (slot)] =                        \
           __builtin_amdgcn_s_memrealtime();                                                          \
   } while (0)
+#define TSDF_STAMP_VAL(iter, slot, val)                                                              \
+  do {                                                                                               \
+    if ((threadIdx.x & (kGW - 1)) == 0 && blockIdx.x < kStampBlocks && (iter) < kStampFrames)                      \
+      g_stamps[(blockIdx.x * kStampFrames + (iter)) * kStampSlots + (slot)] = (val);                 \
+  } while (0)
 #else
 #define TSDF_STAMP(iter, slot) do { } while (0)
+#define TSDF_STAMP_VAL(iter, slot, val) do { } while (0)
 #endif
 
 // ---- raw VALU min/max (no canonicalising v_max x,x,x in front; operands here are never NaN) ----
@@ -528,10 +534,20 @@ __device__ __forceinline__ float f32_round_up(double t) {
 // by it = 1/trunc_dis:  tx = v_x*it - (pix_x-cx)*(pd*kq),  ty likewise,  tz = v_z*it + pd*it (w_z = -pd).
 //   ex[j], ry[j]          rectangle-relative pixel of voxel j (or -1: rejected)
 //   vxs[j], vys, vzs[j]   pre-scaled voxel centre;   negthr[j] = f32_round_up(-v_z)
+// The gather source is either the LDS stage or (rectangles too large for it) the frame in global memory.
+// It is passed with its address space in the type: a generic pointer would make every gather a FLAT load,
+// which is counted in vmcnt together with the volume stores, so each loop iteration would wait for the
+// previous iteration's stores to be acknowledged by memory.  As ds_read the gather only touches lgkmcnt
+// and the stores stay in flight.
+typedef const __attribute__((address_space(3))) float *LdsSrc;
+typedef const __attribute__((address_space(1))) float *GlobalSrc;
+typedef __attribute__((address_space(1))) float *GlobalOut;  // the output volume
+
+template <class SrcP>
 __device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry)[4], const double (&vxs)[4],
                                               const double vys, const double (&vzs)[4],
                                               const float (&negthr)[4], const VoxK &k,
-                                              const float *__restrict__ src, f4 &o0, f4 &o1, f4 &o2) {
+                                              const SrcP src, f4 &o0, f4 &o1, f4 &o2) {
   float pd[4];
   bool inb[4];
 #pragma unroll
@@ -590,14 +606,17 @@ __device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry
 #ifndef TSDF_NT_STORE
 #define TSDF_NT_STORE 1
 #endif
+#ifndef TSDF_TAIL_HELP
+#define TSDF_TAIL_HELP 1
+#endif
 // One 16-byte store of the output volume.  It is written once and never re-read here, so it goes out
 // non-temporal: the depth rows this CU has just streamed stay in L2 / Infinity Cache for the staging
 // copy instead of being evicted by 393 KB of output per frame (measured: 180 -> 155 us per 1024 frames).
-__device__ __forceinline__ void store_vol4(float *p, f4 v) {
+__device__ __forceinline__ void store_vol4(GlobalOut p, f4 v) {
 #if TSDF_NT_STORE
-  __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f4 *)p);
 #else
-  *reinterpret_cast<f4 *>(p) = v;
+  *(__attribute__((address_space(1))) f4 *)p = v;
 #endif
 }
 
@@ -617,11 +636,13 @@ __device__ __forceinline__ int tab_index(int x_or_y, int z, int R) {
   return LAYOUT == 0 ? z * R + x_or_y : x_or_y * R + z;
 }
 
-template <int LAYOUT>
+template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                        const ZEntry *ztab, const int *pxtab, const int *pytab,
-                                       const bool use_tab, const float *__restrict__ src,
-                                       float *__restrict__ out, const int tid) {  // tid within the group
+                                       const bool use_tab, const SrcP src,
+                                       const GlobalOut out, const int tid) {
+  // tid in [0, T): T = kGW when the group works alone, 2*kGW when the CU's other group helps (its
+  // threads come in as kGW + gtid)
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1];
   const int R4 = R / 4;
@@ -630,14 +651,14 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
 
   // slow axis s (z for LAYOUT 0, x for LAYOUT 1); group gi -> (y, fast4)
   int g0, gstep, s0, sstep;
-  if (G <= kGW && (kGW % G) == 0) {
+  if (G <= T && (T % G) == 0) {
     g0 = tid % G;
-    gstep = G;  // one group of 4 voxels per thread, kGW/G slices at a time
+    gstep = G;  // one group of 4 voxels per thread, T/G slices at a time
     s0 = tid / G;
-    sstep = kGW / G;
+    sstep = T / G;
   } else {
     g0 = tid;
-    gstep = kGW;
+    gstep = T;
     s0 = 0;
     sstep = 1;
   }
@@ -731,12 +752,33 @@ struct FrameHdr {
   int64_t off0, off1;
 };
 
+// Tail help: a group that finds the queue empty does not leave at once.  It raises idle[] and waits; the
+// CU's other group, on reaching phase 2 of what is then necessarily its last frame, sees the flag, posts
+// the frame's voxel parameters here and both groups split the slow axis of the volume (the stage and the
+// tables are in LDS, which the two share).  Nothing has to be handed back: the helper leaves when done.
+struct HelpReq {
+  Grid g;
+  VoxK vk;
+  const float *src;  // the frame in global memory (gather source when the rectangle is not staged)
+  float *out;
+  int frame, use_tab, staged, pad;
+};
+
 struct GroupCtl {
   int bar[kGroups];
   int lock;  // 0 free, 1 held: the LDS stage + tables are one resource the two groups take turns on
-  int pad;
+  int help_for;  // 0: none; g+1: group g is asked to help with the frame in `help`
+  int idle[kGroups];
   FrameHdr hdr[kGroups];  // mailbox: the group's first wave fetches the next frame for the others
+  HelpReq help;
 };
+
+__device__ __forceinline__ int lds_load(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(int *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // Work queue: frames beyond the first one per group are handed out dynamically (frame cost varies
 // ~3x with the hand's size; a static 4-frames-per-CU split left a 25 % tail).  One slot per launch in
@@ -762,10 +804,10 @@ __device__ __forceinline__ void group_barrier(int *cnt, int &target) {
 // three products per row, A_i0*v'_x, A_i1*v'_y, A_i2*v'_z, depend on one grid index each and are
 // tabulated per frame (atab, 9*R doubles), leaving ((a + b) + c) + d — the oracle's exact rounding order.
 // atab layout: [axis][index][row] = fl(inv[4*row + axis] * (ori_axis + index*voxel_len)).
-template <int LAYOUT>
+template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
-                                           const double *xf, const double *atab, const float *__restrict__ src,
-                                           float *__restrict__ out, const int tid) {
+                                           const double *xf, const double *atab, const SrcP src,
+                                           const GlobalOut out, const int tid) {
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
   const double *fwd = xf, *inv = xf + 12;
@@ -775,14 +817,14 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
   const int G = R * R4;
   const int64_t R3 = (int64_t)R * R * R;
   int g0, gstep, s0, sstep;
-  if (G <= kGW && (kGW % G) == 0) {
+  if (G <= T && (T % G) == 0) {
     g0 = tid % G;
     gstep = G;
     s0 = tid / G;
-    sstep = kGW / G;
+    sstep = T / G;
   } else {
     g0 = tid;
-    gstep = kGW;
+    gstep = T;
     s0 = 0;
     sstep = 1;
   }
@@ -893,8 +935,9 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
   float *red = red_all[group];
 
   if (tid == 0) {
-    for (int i = 0; i < kGroups; ++i) ctl.bar[i] = 0;
+    for (int i = 0; i < kGroups; ++i) ctl.bar[i] = ctl.idle[i] = 0;
     ctl.lock = 0;
+    ctl.help_for = 0;
   }
   __syncthreads();  // the only workgroup-wide barrier
   int bar_target = 0;
@@ -1030,6 +1073,11 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         zero_volume(out, R, gtid);
       } else {
         ran_phase2 = true;
+        // The thread's index for the tables and the voxel pass, hidden from loop-invariant code motion:
+        // otherwise every constant derived from it (a dozen float64 conversions of voxel indices) is
+        // computed once before the frame loop and then occupies registers, or scratch, all through phase 1.
+        int vt = gtid;
+        asm volatile("" : "+v"(vt));
         VoxK vk;
         vk.cx = cam.cx;
         vk.cy = cam.cy;
@@ -1050,19 +1098,19 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         const double vl = (double)g.voxel_len;
         const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
         TSDF_STAMP(kGroups * iter + group, 5);
-        if (gtid < R) {
-          const double v_z = oz + (double)gtid * vl;  // :28
+        if (vt < R) {
+          const double v_z = oz + (double)vt * vl;  // :28
           ZEntry ze;
           ze.q = -cam.focal / v_z;                    // :30
           ze.vzs = v_z * vk.it;
           ze.negthr = f32_round_up(-v_z);             // pd < -v_z  <=>  w_z > v_z  (:65)
           ze.pad = 0.f;
-          ztab[gtid] = ze;
+          ztab[vt] = ze;
         }
         if constexpr (AUG) {
           // products of the inverse map, one per (axis, index, row): see phase2_aug
           const double *inv = xforms + 24 * (int64_t)frame + 12;
-          for (int e = gtid; e < 9 * R; e += kGW) {
+          for (int e = vt; e < 9 * R; e += kGW) {
             const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
             const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
             atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
@@ -1070,7 +1118,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         }
         const bool use_tab = !AUG && R <= kTabR;  // uniform
         if (use_tab) {
-          for (int e = gtid; e < R * R; e += kGW) {
+          for (int e = vt; e < R * R; e += kGW) {
             const int z = e / R, i = e - z * R;
             const double q = -cam.focal / (oz + (double)z * vl);                              // :30
             const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
@@ -1130,15 +1178,53 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is counted in vmcnt
         }
         TSDF_STAMP(kGroups * iter + group, 7);
+        if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
+          if (gwave == 0 && lane == 0) ctl.hdr[group].pad = lds_load(&ctl.idle[group ^ 1]);
+        }
         gsync();
         TSDF_STAMP(kGroups * iter + group, 8);
-        const float *gsrc = staged ? stage : f.depth;
         vk.stride = staged ? sw4 : f.bw;
         vk.base = staged ? 0 : ab.r0 * f.bw + ab.c0;
-        if constexpr (AUG) {
-          phase2_aug<LAYOUT>(g, cam, vk, R, xforms + 24 * (int64_t)frame, atab, gsrc, out, gtid);
+        bool helped = false;  // group-uniform
+        if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
+          // the other group is idle (so this is the launch's last frame on this CU): split the volume with it
+          if (__builtin_amdgcn_readfirstlane(ctl.hdr[group].pad)) {
+            helped = true;
+            if (gwave == 0 && lane == 0) {
+              HelpReq hq;
+              hq.g = g;
+              hq.vk = vk;
+              hq.src = f.depth;
+              hq.staged = staged;
+              hq.pad = 0;
+              hq.out = out;
+              hq.frame = frame;
+              hq.use_tab = use_tab;
+              ctl.help = hq;
+              lds_store(&ctl.help_for, (group ^ 1) + 1);
+            }
+          }
+        }
+        TSDF_STAMP_VAL(kGroups * iter + group, 10, helped ? 2 : 1);
+        auto run2 = [&](auto src) {
+          if (__builtin_expect(helped, 0)) {
+            if constexpr (AUG) {
+              phase2_aug<LAYOUT, 2 * kGW>(g, cam, vk, R, xforms + 24 * (int64_t)frame, atab, src, (GlobalOut)out, vt);
+            } else {
+              phase2<LAYOUT, 2 * kGW>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, src, (GlobalOut)out, vt);
+            }
+          } else {
+            if constexpr (AUG) {
+              phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xforms + 24 * (int64_t)frame, atab, src, (GlobalOut)out, vt);
+            } else {
+              phase2<LAYOUT, kGW>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, src, (GlobalOut)out, vt);
+            }
+          }
+        };
+        if (staged) {
+          run2((LdsSrc)stage);
         } else {
-          phase2<LAYOUT>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, gsrc, out, gtid);
+          run2((GlobalSrc)f.depth);
         }
       }
     }
@@ -1150,6 +1236,43 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     (void)ran_phase2;
     if (holds_stage && gwave == 0 && lane == 0)
       __hip_atomic_store(&ctl.lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // ---- queue empty: offer help with the other group's last frame before leaving ----
+  if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
+    // Queue empty: wait until the other group either asks for help with its last frame or is idle too.
+    // (help_for is written before idle[] by the same wave, and LDS operations of a wave stay in order:
+    // once idle[other] reads 1, help_for is final.)
+    if (gwave == 0 && lane == 0) {
+      lds_store(&ctl.idle[group], 1);
+      int dec;
+      for (;;) {
+        if (lds_load(&ctl.help_for) == group + 1) { dec = 1; break; }
+        if (lds_load(&ctl.idle[group ^ 1])) { dec = lds_load(&ctl.help_for) == group + 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      ctl.hdr[group].pad = dec;
+    }
+    gsync();
+    if (__builtin_amdgcn_readfirstlane(ctl.hdr[group].pad)) {
+      const HelpReq hq = ctl.help;
+      // pointers that came through LDS are generic: say that they are global, or every access through
+      // them is a FLAT instruction (counted in lgkmcnt as well as vmcnt)
+      const GlobalOut hout = (GlobalOut)hq.out;
+      const GlobalSrc hsrc = (GlobalSrc)hq.src;
+      auto run2 = [&](auto src) {
+        if constexpr (AUG) {
+          phase2_aug<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, xforms + 24 * (int64_t)hq.frame, atab, src, hout,
+                                      kGW + gtid);
+        } else {
+          phase2<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, ztab, pxtab, pytab, hq.use_tab != 0, src, hout, kGW + gtid);
+        }
+      };
+      if (hq.staged) {
+        run2((LdsSrc)stage);
+      } else {
+        run2(hsrc);
+      }
+    }
   }
   // ---- leave: the last group of the launch returns the queue slot to its initial state ----
   if (gwave == 0 && lane == 0) {
