@@ -349,6 +349,28 @@ def test_many_small_crops_exercise_the_work_queue(pkg, synth):
     np.testing.assert_array_equal(out1.max_l[:250].cpu().numpy(), ref["max_l"])
 
 
+@pytest.mark.parametrize("n", [513, 600, 777, 1030])
+def test_tail_of_the_queue(pkg, synth, n):
+    """Batch sizes a little beyond one frame per group (512 on a 256-CU part): the last frames are handed
+    out one frame ahead, groups run dry at different times and the idle group of a CU helps the other one
+    with its remaining volumes.  Every frame must match the oracle, in every repeat, both layouts."""
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=7000 + n)
+    ref = oracle.voxelize(depth, off, hdr, R=32, n_threads=8)
+    d = dev()
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    for rep in range(6):
+        out = pkg.voxelize(td, to, th)
+        torch.cuda.synchronize()
+        err = np.abs(out.tsdf.cpu().numpy() - ref["tsdf"]).reshape(n, -1).max(axis=1)
+        assert err.max() <= TOL, (rep, np.nonzero(err > TOL)[0][:10])
+        np.testing.assert_array_equal(out.mid_p.cpu().numpy(), ref["mid_p"])
+    ref1 = oracle.voxelize(depth, off, hdr, R=32, layout=1, n_threads=8)
+    for rep in range(2):
+        out = pkg.voxelize(td, to, th, layout="cxyz")
+        torch.cuda.synchronize()
+        assert np.abs(out.tsdf.cpu().numpy() - ref1["tsdf"]).max() <= TOL
+
+
 def test_concurrent_streams_and_graph_replay(pkg, synth):
     """Launches on two streams at once use different queue slots; a captured launch replays correctly."""
     d = dev()
