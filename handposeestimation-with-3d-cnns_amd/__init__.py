@@ -13,7 +13,7 @@ Host side:                               packing (MSRA .bin reader / batch packe
 from . import _lib  # noqa: F401
 from ._lib import TsdfCam, TsdfError, default_cam  # noqa: F401
 from .voxelize import AabbBatch, TsdfBatch, aabb, voxelize, voxelize_aug, voxelize_grid  # noqa: F401
-from . import augment, dataset, packing, shard, synth  # noqa: F401
+from . import augment, dataset, export, packing, shard, synth  # noqa: F401
 from .dataset import MSRADepthDataset, VoxelLoader, denormalize_joints, normalize_joints  # noqa: F401
 from .tsdf_numba import cal_tsdf_cuda  # noqa: F401
 from .tsdf_for import tsdf_cal, tsdf_f  # noqa: F401

@@ -177,6 +177,53 @@ def test_on_the_fly_dataset_split_and_items(pkg, synth, tmp_path):
         pkg.MSRADepthDataset(str(tmp_path), size="medium")
 
 
+def test_offline_export_writes_the_reference_schema(pkg, synth, tmp_path):
+    """export.preprocess_tree: the files pre/read_MSRA.py:117-139 writes and 3D_CNN/dataset.py:93-131 reads
+    (names, keys, shapes, scalar counts).  The voxelizer is injected (the oracle) so that the file handling
+    is checked without a GPU; without the injection the call needs the HIP device."""
+    import oracle
+
+    db, out = tmp_path / "db", tmp_path / "result"
+    db.mkdir()
+    total = _make_msra_tree(pkg, synth, db, n_sub=2, n_ges=2, n_frames=3)
+
+    def fake(pk, res, layout, device):
+        r = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=res, layout=0 if layout == "czyx" else 1)
+        return r["tsdf"], r["max_l"], r["mid_p"], r["status"]
+
+    totals = pkg.export.preprocess_tree(str(db), str(out), points_num=500, voxelize_fn=fake,
+                                        rng=np.random.default_rng(1))
+    assert totals == {"P0": 6, "P1": 6} and sum(totals.values()) == total
+    for sub in ("P0", "P1"):
+        assert int(np.load(out / f"data_num-{sub}.npy")) == 6
+        for d in ("Point_Cloud", "TSDF", "ground_truth", "num"):
+            assert sorted(os.listdir(out / sub / d)) == ["1.np" + ("z" if d == "TSDF" else "y"),
+                                                         "2.np" + ("z" if d == "TSDF" else "y")]
+        z = np.load(out / sub / "TSDF" / "1.npz")
+        assert z["tsdf"].shape == (3, 3, 32, 32, 32) and z["tsdf"].dtype == np.float32
+        assert z["max_l"].shape == (3,) and z["mid_p"].shape == (3, 3) and not z["status"].any()
+        assert np.load(out / sub / "ground_truth" / "1.npy").shape == (3, 63)
+        assert int(np.load(out / sub / "num" / "2.npy")) == 3
+        pc = np.load(out / sub / "Point_Cloud" / "1.npy")
+        assert pc.shape == (3, 500, 3) and np.all(pc[:, :, 2] < 0)       # z = -depth, every point a valid pixel
+    # the stored volume is the loop layout [c,x,y,z] (what the reference writer produced) ...
+    pk = pkg.packing.pack_bin_files(pkg.packing.gesture_bin_paths(str(db / "P0" / "1")))
+    ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32, layout=0)
+    z = np.load(out / "P0" / "TSDF" / "1.npz")
+    np.testing.assert_array_equal(z["tsdf"], ref["tsdf"].transpose(0, 1, 4, 3, 2))
+    # ... and the switches: numba layout, float64, [n,21,3] labels, no point clouds
+    out2 = tmp_path / "result2"
+    pkg.export.preprocess_tree(str(db), str(out2), layout="czyx", dtype=np.float64, gt_3d=True,
+                               point_clouds=False, subjects=["P1"], gestures=["2"], voxelize_fn=fake)
+    z = np.load(out2 / "P1" / "TSDF" / "2.npz")
+    assert z["tsdf"].dtype == np.float64 and os.listdir(out2 / "P1" / "Point_Cloud") == []
+    assert np.load(out2 / "P1" / "ground_truth" / "2.npy").shape == (3, 21, 3)
+    # no injection, no GPU here: must fail loudly, not fall back
+    if not torch.cuda.is_available():
+        with pytest.raises((ValueError, RuntimeError, AssertionError, pkg.TsdfError)):
+            pkg.export.preprocess_tree(str(db), str(tmp_path / "r3"), device="cpu", point_clouds=False)
+
+
 def test_joint_normalisation_matches_reference_formula(pkg):
     """(gt - mid_p) / max_l + 0.5 per joint (pre/joint_nor.py:8-18) and its inverse."""
     rng = np.random.default_rng(2)

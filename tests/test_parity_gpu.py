@@ -302,6 +302,33 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
     assert seen == 8 and len(loader) == 3
 
 
+def test_offline_export_on_the_gpu(pkg, synth, tmp_path):
+    """export.preprocess_tree with the HIP voxelizer (one launch per gesture): files in the reference's
+    schema whose contents equal the oracle on the same .bin files."""
+    db, out = tmp_path / "db", tmp_path / "result"
+    rng = np.random.default_rng(3)
+    for g in ("1", "2"):
+        gdir = db / "P0" / g
+        gdir.mkdir(parents=True)
+        with open(gdir / "joint.txt", "w") as f:
+            f.write("5\n")
+            for row in rng.normal(0, 60, (5, 63)):
+                f.write(" ".join(f"{v:.6f}" for v in row) + "\n")
+        for i in range(5):
+            h, d = synth.synth_frame(4000 + 10 * int(g) + i, "crop")
+            pkg.packing.write_bin(str(gdir / ("%06d_depth.bin" % i)), h, d)
+    totals = pkg.export.preprocess_tree(str(db), str(out), points_num=100, device=dev())
+    assert totals == {"P0": 10}
+    for g in ("1", "2"):
+        pk = pkg.packing.pack_bin_files(pkg.packing.gesture_bin_paths(str(db / "P0" / g)))
+        ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32, layout=1)
+        z = np.load(out / "P0" / "TSDF" / f"{g}.npz")
+        assert np.abs(z["tsdf"] - ref["tsdf"]).max() <= TOL
+        np.testing.assert_array_equal(z["max_l"], ref["max_l"])
+        np.testing.assert_array_equal(z["mid_p"], ref["mid_p"])
+        assert not z["status"].any()
+
+
 def test_large_rectangle_falls_back_to_global_gather(pkg):
     """A valid-pixel rectangle over 32 Ki pixels does not fit the LDS stage: the gather then reads the
     crop from global memory.  Same results."""
