@@ -147,6 +147,44 @@ def test_edge_cases(pkg, synth):
             assert not got["tsdf"][i].any() and got["max_l"][i] == 0
 
 
+def test_random_geometry_sweep(pkg):
+    """240 frames of random geometry in one batch against the oracle: bbox widths around every lane/vector
+    boundary of the row pass (1..5 columns per lane, the 320-column pass limit, multi-pass rows), heights
+    1..200, bboxes hanging off the principal point on every side, sparse to dense validity, negative and
+    sub-threshold depths, near and far hands (different grid scales)."""
+    rng = np.random.default_rng(20260)
+    widths = [1, 2, 3, 4, 5, 7, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 319, 320, 321,
+              383, 384, 385, 449, 640, 645]
+    frames = []
+    for k in range(240):
+        bw = widths[k % len(widths)]
+        bh = int(rng.integers(1, 200)) if bw * 200 < 60000 else int(rng.integers(1, 60000 // bw))
+        left, top = int(rng.integers(-40, 400)), int(rng.integers(-40, 300))
+        base = float(rng.uniform(150, 1500))
+        d = (base + rng.normal(0, base * 0.05, (bh, bw))).astype(np.float32)
+        keep = rng.random((bh, bw)) < rng.choice([0.02, 0.3, 0.9, 1.0])
+        # an elliptical blob for most frames, scattered pixels for the others
+        if k % 3:
+            yy, xx = np.mgrid[0:bh, 0:bw]
+            cy, cx = rng.uniform(0, bh), rng.uniform(0, bw)
+            ry, rx = rng.uniform(1, bh + 1), rng.uniform(1, bw + 1)
+            keep &= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        d[~keep] = 0.0
+        if k % 7 == 0:
+            d *= -1.0
+        if k % 11 == 0:
+            d[rng.random((bh, bw)) < 0.1] = 0.75          # |d| < 1: invalid by the rule of tsdf_numba.py:40,87
+        frames.append((np.array([640, 480, left, top, left + bw, top + bh], np.int32), d.reshape(-1)))
+    headers = np.stack([f[0] for f in frames])
+    offsets = np.zeros(len(frames) + 1, np.int64)
+    offsets[1:] = np.cumsum([f[1].size for f in frames])
+    depth = np.concatenate([f[1] for f in frames])
+    for layout in ("czyx", "cxyz"):
+        got, ref, _, _ = compare(pkg, depth, offsets, headers, 32, layout)
+        assert (got["status"] == 0).sum() > 150           # the sweep is mostly real work, not degenerate frames
+    compare(pkg, depth, offsets, headers, 48, "czyx")      # a resolution without projection tables
+
+
 def test_empty_batch(pkg):
     d = dev()
     out = pkg.voxelize(torch.zeros(0, device=d), torch.zeros(1, dtype=torch.int64, device=d),
