@@ -1,0 +1,142 @@
+/*
+ * abi_host.c — the C ABI of include/tsdf.h driven from plain C: hipMalloc'd buffers, a HIP stream, no Python and
+ * no torch anywhere in the process.  Test program (tests/test_parity_gpu.py::test_plain_c_host_program builds and
+ * runs it on the GPU box); it links the oracle as the checker, which only tests may do.
+ *
+ *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ abi_host.c -I/opt/rocm/include -I../../include -L<pkg> -ltsdf_hip \
+ *       -L../../oracle -ltsdf_oracle -L/opt/rocm/lib -lamdhip64 -lm -o abi_host
+ *
+ * Frames: synthetic "hand" blobs generated here (seeded LCG), three crops of different sizes.
+ * Checks: return codes, per-frame status, max_l / mid_p bit-exact, volume <= 1e-5 against the oracle, both
+ * layouts, tsdf_aabb_hip, argument validation, n = 0.  Prints one line per check; exit code 0 = all passed.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tsdf.h"
+
+/* oracle/tsdf_oracle.c (test infrastructure) */
+int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32_t *headers, int n, int R,
+                         const tsdf_cam *cam, int layout, int n_threads, float *out_tsdf, float *out_max_l,
+                         float *out_mid_p, int32_t *out_status, float *out_aabb, float *out_grid, float *out_ori);
+
+#define HIP(x)                                                                       \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      printf("FAIL %s: %s\n", #x, hipGetErrorString(e_));                            \
+      return 2;                                                                      \
+    }                                                                                \
+  } while (0)
+
+static uint32_t lcg_state = 12345u;
+static float frand(void) { /* [0,1) */
+  lcg_state = lcg_state * 1664525u + 1013904223u;
+  return (float)(lcg_state >> 8) / 16777216.0f;
+}
+
+static int failures = 0;
+static void check(int ok, const char *what) {
+  printf("%s %s\n", ok ? "ok  " : "FAIL", what);
+  if (!ok) ++failures;
+}
+
+int main(void) {
+  enum { N = 3, R = 32 };
+  const int bw[N] = {97, 160, 320}, bh[N] = {120, 131, 240};
+  const int left[N] = {100, 40, 0}, top[N] = {60, 30, 0};
+  int32_t headers[N][6];
+  int64_t offsets[N + 1];
+  offsets[0] = 0;
+  for (int i = 0; i < N; ++i) {
+    const int32_t h[6] = {320, 240, left[i], top[i], left[i] + bw[i], top[i] + bh[i]};
+    memcpy(headers[i], h, sizeof h);
+    offsets[i + 1] = offsets[i] + (int64_t)bw[i] * bh[i];
+  }
+  const int64_t total = offsets[N];
+  float *depth = (float *)calloc((size_t)total, sizeof(float));
+  for (int i = 0; i < N; ++i) {
+    const float cx = bw[i] * (0.3f + 0.4f * frand()), cy = bh[i] * (0.3f + 0.4f * frand());
+    const float rad = 0.3f * (float)(bw[i] < bh[i] ? bw[i] : bh[i]), base = 350.f + 200.f * frand();
+    for (int y = 0; y < bh[i]; ++y)
+      for (int x = 0; x < bw[i]; ++x) {
+        const float dx = (x - cx) / rad, dy = (y - cy) / rad, rr = dx * dx + dy * dy;
+        if (rr <= 1.f && frand() > 0.01f)
+          depth[offsets[i] + (int64_t)y * bw[i] + x] = base - 50.f * sqrtf(1.f - rr) + frand();
+      }
+  }
+
+  const size_t vol = (size_t)3 * R * R * R;
+  float *ref_t = (float *)malloc(N * vol * sizeof(float)), *got_t = (float *)malloc(N * vol * sizeof(float));
+  float ref_l[N], ref_m[N][3], got_l[N], got_m[N][3], ref_ab[N][6], got_ab[N][6];
+  int32_t ref_s[N], got_s[N];
+
+  check(tsdf_version() == TSDF_ABI_VERSION, "tsdf_version() == TSDF_ABI_VERSION");
+  check(tsdf_resolution_supported(32) && !tsdf_resolution_supported(30), "tsdf_resolution_supported");
+  tsdf_cam cam;
+  tsdf_default_cam(&cam);
+  check(cam.focal == 241.42 && cam.cx == 160 && cam.cy == 120, "tsdf_default_cam");
+
+  float *d_depth, *d_t, *d_l, *d_m, *d_ab;
+  int64_t *d_off;
+  int32_t *d_hdr, *d_s;
+  hipStream_t stream;
+  HIP(hipStreamCreate(&stream));
+  HIP(hipMalloc((void **)&d_depth, (size_t)total * 4));
+  HIP(hipMalloc((void **)&d_off, sizeof offsets));
+  HIP(hipMalloc((void **)&d_hdr, sizeof headers));
+  HIP(hipMalloc((void **)&d_t, N * vol * 4));
+  HIP(hipMalloc((void **)&d_l, N * 4));
+  HIP(hipMalloc((void **)&d_m, N * 12));
+  HIP(hipMalloc((void **)&d_s, N * 4));
+  HIP(hipMalloc((void **)&d_ab, N * 24));
+  HIP(hipMemcpyAsync(d_depth, depth, (size_t)total * 4, hipMemcpyHostToDevice, stream));
+  HIP(hipMemcpyAsync(d_off, offsets, sizeof offsets, hipMemcpyHostToDevice, stream));
+  HIP(hipMemcpyAsync(d_hdr, headers, sizeof headers, hipMemcpyHostToDevice, stream));
+
+  for (int layout = 0; layout < 2; ++layout) {
+    tsdf_oracle_voxelize(depth, offsets, &headers[0][0], N, R, NULL, layout, 1, ref_t, ref_l, &ref_m[0][0], ref_s,
+                         &ref_ab[0][0], NULL, NULL);
+    const int rc = tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, N, R, NULL, layout, stream, d_t, d_l, d_m, d_s);
+    check(rc == TSDF_OK, layout ? "tsdf_voxelize_hip [c,x,y,z] returns TSDF_OK" : "tsdf_voxelize_hip [c,z,y,x] returns TSDF_OK");
+    HIP(hipMemcpyAsync(got_t, d_t, N * vol * 4, hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(got_l, d_l, N * 4, hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(got_m, d_m, N * 12, hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(got_s, d_s, N * 4, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    check(memcmp(got_s, ref_s, sizeof got_s) == 0 && got_s[0] == TSDF_FRAME_OK, "  per-frame status");
+    check(memcmp(got_l, ref_l, sizeof got_l) == 0, "  max_l bit exact");
+    check(memcmp(got_m, ref_m, sizeof got_m) == 0, "  mid_p bit exact");
+    double worst = 0;
+    for (size_t k = 0; k < N * vol; ++k) {
+      const double e = fabs((double)got_t[k] - (double)ref_t[k]);
+      if (e > worst) worst = e;
+    }
+    printf("     max |hip - oracle| = %.3g\n", worst);
+    check(worst <= 1e-5, "  volume within 1e-5 of the oracle");
+  }
+
+  check(tsdf_aabb_hip(d_depth, total, d_off, d_hdr, N, R, NULL, stream, d_ab, NULL, NULL, d_s) == TSDF_OK,
+        "tsdf_aabb_hip returns TSDF_OK");
+  HIP(hipMemcpyAsync(got_ab, d_ab, N * 24, hipMemcpyDeviceToHost, stream));
+  HIP(hipStreamSynchronize(stream));
+  check(memcmp(got_ab, ref_ab, sizeof got_ab) == 0, "  AABB bit exact");
+
+  check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, 0, R, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_OK,
+        "n = 0 is a no-op");
+  check(tsdf_voxelize_hip(NULL, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_ERR_INVALID_ARG,
+        "NULL depth -> TSDF_ERR_INVALID_ARG");
+  check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, N, 30, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_ERR_INVALID_ARG,
+        "unsupported R -> TSDF_ERR_INVALID_ARG");
+  check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 7, stream, d_t, d_l, d_m, d_s) == TSDF_ERR_INVALID_ARG,
+        "unknown layout -> TSDF_ERR_INVALID_ARG");
+  check(strlen(tsdf_strerror(TSDF_ERR_INVALID_ARG)) > 0 && strlen(tsdf_strerror(-99)) > 0, "tsdf_strerror");
+  HIP(hipStreamSynchronize(stream));
+  HIP(hipStreamDestroy(stream));
+  printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
+  return failures ? 1 : 0;
+}

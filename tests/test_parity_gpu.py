@@ -147,6 +147,32 @@ def test_edge_cases(pkg, synth):
             assert not got["tsdf"][i].any() and got["max_l"][i] == 0
 
 
+def test_plain_c_host_program(pkg, tmp_path):
+    """The boundary is a C ABI: tests/abi_host/abi_host.c drives libtsdf_hip.so from plain C (gcc, hipMalloc'd
+    buffers, its own stream; no Python or torch in that process) and checks every entry point against the
+    oracle.  Built here with the box's gcc and run as a child process."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "handposeestimation-with-3d-cnns_amd")
+    ora_dir = os.path.join(root, "oracle")
+    oracle.lib()  # makes sure libtsdf_oracle.so is built
+    exe = str(tmp_path / "abi_host")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "abi_host", "abi_host.c"),
+           "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(root, "include"),
+           "-L" + pkg_dir, "-ltsdf_hip", "-L" + ora_dir, "-ltsdf_oracle", "-L" + os.path.join(rocm, "lib"),
+           "-lamdhip64", "-lm", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join(
+        [pkg_dir, ora_dir, os.path.join(rocm, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    sys.stdout.write(r.stdout)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("ok  ") >= 20 and "FAIL" not in r.stdout
+
+
 def test_random_geometry_sweep(pkg):
     """240 frames of random geometry in one batch against the oracle: bbox widths around every lane/vector
     boundary of the row pass (1..5 columns per lane, the 320-column pass limit, multi-pass rows), heights
