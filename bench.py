@@ -105,15 +105,23 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the voxelizer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TSDF_BENCH_REHEARSAL=1: dry run of the N>1 code path on a box with fewer GPUs than ranks (ranks share
+    # devices, the barrier / max-of-elapsed go over gloo instead of RCCL, the line says "rehearsal": true).
+    # Never set by the driver; a rehearsal number is not a measurement.
+    rehearsal = os.environ.get("TSDF_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         # launched by torch.distributed.run: RCCL for the start/stop barrier + max of elapsed only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
     synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
@@ -128,7 +136,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -148,7 +156,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -205,12 +213,14 @@ def main():
                 "single_launch_ms_min": round(float(kern_ms.min()), 4),
             },
         }
+        if rehearsal:
+            line["rehearsal"] = True
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(depth, offsets, headers)
         print(json.dumps(line), flush=True)
 
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
