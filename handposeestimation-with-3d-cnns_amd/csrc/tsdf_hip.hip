@@ -40,6 +40,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <atomic>
 #include <type_traits>
@@ -1299,13 +1300,25 @@ int num_cus() {
   return cached[dev];
 }
 
+// The code object holds gfx950 kernels only: any other device is "no usable device", not a launch error.
+// (Cached per device id; a racing first call computes the same value.)
 int check_device() {
+  static int arch_state[64] = {0};  // 0 unknown, 1 gfx950, -1 something else
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return TSDF_ERR_NO_DEVICE;
   }
-  return TSDF_OK;
+  if (dev < 0 || dev >= 64) return TSDF_OK;  // beyond the cache: let the launch decide
+  if (arch_state[dev] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return TSDF_ERR_NO_DEVICE;
+    }
+    arch_state[dev] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : -1;
+  }
+  return arch_state[dev] == 1 ? TSDF_OK : TSDF_ERR_NO_DEVICE;
 }
 
 // everything a launch needs, so that the dispatch over (R, layout, augmented) stays in one place

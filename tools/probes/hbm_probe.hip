@@ -41,6 +41,32 @@ __global__ __launch_bounds__(1024) void k_mix(const f4 *__restrict__ a, f4 *__re
   if (acc.x == 12345.678f) *sink = 1.f;
 }
 
+// Volume-shaped writes: 512-thread groups each write whole 32^3 x 3 float volumes (393,216 B) either as one
+// contiguous stream or the way the voxel pass does (thread -> 4 x-voxels, z pairs, the 3 channel planes 128 KiB
+// apart written back to back).  Tells whether the [c][z][y][x] plane stride costs anything at the HBM.
+template <bool NT, bool PLANES>
+__global__ __launch_bounds__(1024) void k_volumes(f4 *__restrict__ out, int n_frames) {
+  const int group = threadIdx.x >> 9, t = threadIdx.x & 511;
+  const f4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+  for (int fr = blockIdx.x * 2 + group; fr < n_frames; fr += gridDim.x * 2) {
+    f4 *o = out + (size_t)fr * (3 * 32768 / 4);
+    if (PLANES) {
+      const int gi = t & 255, s0 = t >> 8;           // (y, x4) and the z parity
+      for (int z = s0; z < 32; z += 2) {
+        const int e4 = (z * 32 * 32 + gi * 4) / 4;   // float4 index inside a plane
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (NT) __builtin_nontemporal_store(v, o + c * 8192 + e4); else o[c * 8192 + e4] = v;
+        }
+      }
+    } else {
+      for (int i = t; i < 3 * 8192; i += 512) {
+        if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+      }
+    }
+  }
+}
+
 int main(int argc, char **argv) {
   const size_t bytes = (argc > 1 ? atoll(argv[1]) : 1024) << 20;
   const size_t n4 = bytes / 16;
@@ -68,6 +94,22 @@ int main(int argc, char **argv) {
     const size_t nr4 = n4 * 307200 / 393216;
     run("read then write 307:393", [&] { hipLaunchKernelGGL(k_mix<false>, grid, 1024, 0, 0, a, b, nr4, n4, sink); }, 16.0 * (nr4 + n4));
     run("same, nt stores", [&] { hipLaunchKernelGGL(k_mix<true>, grid, 1024, 0, 0, a, b, nr4, n4, sink); }, 16.0 * (nr4 + n4));
+  }
+  {
+    const int nf = (int)(bytes / 393216);
+    auto runv = [&](const char *name, auto launch) {
+      for (int i = 0; i < 3; ++i) launch();
+      (void)hipEventRecord(e0, 0);
+      for (int i = 0; i < K; ++i) launch();
+      (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("volumes x%d  %-34s %8.1f us  %7.1f GB/s\n", nf, name, ms / K * 1e3, (double)nf * 393216 / (ms / K * 1e-3) / 1e9);
+    };
+    const int grid = p.multiProcessorCount;
+    runv("contiguous", [&] { hipLaunchKernelGGL((k_volumes<false, false>), grid, 1024, 0, 0, b, nf); });
+    runv("contiguous nt", [&] { hipLaunchKernelGGL((k_volumes<true, false>), grid, 1024, 0, 0, b, nf); });
+    runv("3 planes 128 KiB apart", [&] { hipLaunchKernelGGL((k_volumes<false, true>), grid, 1024, 0, 0, b, nf); });
+    runv("3 planes 128 KiB apart nt", [&] { hipLaunchKernelGGL((k_volumes<true, true>), grid, 1024, 0, 0, b, nf); });
   }
   CK(hipDeviceSynchronize());
   printf("device: %s, %d CUs\n", p.name, p.multiProcessorCount);
