@@ -56,9 +56,9 @@ def host_threads() -> int:
     return max(1, min(avail, 16))
 
 
-def cpu_baseline(depth, offsets, headers, single_s=5.0, multi_s=2.5):
-    """Time the oracle on host cores over the same frames: ~5 s on one thread plus ~2.5 s wall on all
-    threads (about 10-30 s of CPU work).  Whole passes over the 1024-frame batch are repeated until
+def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
+    """Time the oracle on host cores over the same frames: ~4 s on one thread plus ~1.5 s wall on all
+    threads (16 on the GPU box: about 28 s of CPU work in total).  Whole passes over the 1024-frame batch are repeated until
     the leg's budget is used, so the sample is always a multiple of the bench workload."""
     import oracle  # test infrastructure; used here only as the reported CPU baseline
 
