@@ -166,16 +166,13 @@ __device__ __forceinline__ double mul_then_add(double a, double b, double c) {
   return p + c;
 }
 
-// o = A p + b for one row {A_i0, A_i1, A_i2, b_i}: products and sums rounded separately, in this order
-// (the augmented form's arithmetic contract, oracle/tsdf_oracle.c::affine3).
+// Forward map, one row {A_i0, A_i1, A_i2, b_i}: o = fma(A_i0, x, fma(A_i1, y, fma(A_i2, z, b_i))) — the augmented
+// form's arithmetic contract (oracle/tsdf_oracle.c::affine3_fwd).  Three instructions per row; with the
+// identity row {1,0,0,0} it returns x exactly, so the identity map reproduces the plain path bit for bit.
+// (The inverse map is specified with separately rounded products instead, because those can be tabulated
+// per grid index: see phase2_aug.)
 __device__ __forceinline__ double affine_row(const double *m, double px, double py, double pz) {
-#pragma clang fp contract(off)
-  double a = m[0] * px;
-  double b = m[1] * py;
-  double c = m[2] * pz;
-  double s = a + b;
-  s = s + c;
-  return s + m[3];
+  return __builtin_fma(m[0], px, __builtin_fma(m[1], py, __builtin_fma(m[2], pz, m[3])));
 }
 
 // fl64(d / F) without the hardware division sequence (~12 dependent float64 instructions):
@@ -859,36 +856,41 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         pd[j] = src[idx];                                                        // :38-39
         ok[j] = inb & (__builtin_fabsf(pd[j]) >= vk.eps);                        // :40
       }
-      // ---- z component first: a wave whose voxels are all rejected or beyond the truncation distance
-      // along z' alone needs nothing else (dist >= |tz| > 1 -> (1,1,1)) ----
+      // ---- z component first: a wave whose voxels are all beyond the truncation distance along z' alone
+      // needs nothing else (dist >= |tz| > 1 -> (1,1,1)); one whose voxels are all rejected needs nothing ----
       double wx[4], wy[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        q2[j] = div_by_focal((double)pd[j], cam);                                // :43
-        wx[j] = ((double)(ex[j] + vk.px0) - cam.cx) * q2[j];                     // :44
-        wy[j] = -((double)(ry[j] + vk.py0) - cam.cy) * q2[j];                    // :45
-        az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
-        tz[j] = (vpz[j] - az[j]) * vk.it;                                        // :49
-        any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
-      }
       float o0[4], o1[4], o2[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o0[j] = o1[j] = o2[j] = 1.0f;
-      if (__any(any_near)) {
+      for (int j = 0; j < 4; ++j) {
+        o0[j] = o1[j] = o2[j] = 1.0f;
+        az[j] = vpz[j];
+      }
+      if (__any(ok[0] | ok[1] | ok[2] | ok[3])) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const double wz = -(double)pd[j];
-          const double ax = affine_row(fwd + 0, wx[j], wy[j], wz);
-          const double ay = affine_row(fwd + 4, wx[j], wy[j], wz);
-          const double tx = (vpx[j] - ax) * vk.it, ty = (vpy - ay) * vk.it;      // :47-48
-          const double s2 = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));
-          const bool nearv = s2 <= 1.0;                                          // :54
-          const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
-          const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
-          const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
-          o0[j] = nearv ? m0 : 1.0f;
-          o1[j] = nearv ? m1 : 1.0f;
-          o2[j] = nearv ? m2 : 1.0f;
+          q2[j] = div_by_focal((double)pd[j], cam);                                // :43
+          wx[j] = ((double)(ex[j] + vk.px0) - cam.cx) * q2[j];                     // :44
+          wy[j] = -((double)(ry[j] + vk.py0) - cam.cy) * q2[j];                    // :45
+          az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
+          tz[j] = (vpz[j] - az[j]) * vk.it;                                        // :49
+          any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
+        }
+        if (__any(any_near)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double wz = -(double)pd[j];
+            const double ax = affine_row(fwd + 0, wx[j], wy[j], wz);
+            const double ay = affine_row(fwd + 4, wx[j], wy[j], wz);
+            const double tx = (vpx[j] - ax) * vk.it, ty = (vpy - ay) * vk.it;      // :47-48
+            const double s2 = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));
+            const bool nearv = s2 <= 1.0;                                          // :54
+            const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
+            const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
+            const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
+            o0[j] = nearv ? m0 : 1.0f;
+            o1[j] = nearv ? m1 : 1.0f;
+            o2[j] = nearv ? m2 : 1.0f;
+          }
         }
       }
 #pragma unroll

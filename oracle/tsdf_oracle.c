@@ -265,8 +265,16 @@ int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32
  *           the surface point w of that pixel (:43-46) is mapped forward, w' = T(w), and the
  *           truncated distances (:47-68) are taken between v' and w'.
  */
+/* Inverse map (voxel centre back into the camera frame): products rounded one by one, summed left to right —
+ * a form whose products depend on one grid index each, so an implementation may tabulate them. */
 static void affine3(const double *m, const double *p, double *o) {
   for (int i = 0; i < 3; ++i) o[i] = ((m[4 * i] * p[0] + m[4 * i + 1] * p[1]) + m[4 * i + 2] * p[2]) + m[4 * i + 3];
+}
+
+/* Forward map (camera-frame point into the augmented frame): a fused chain, one rounding per step.  With the
+ * identity row {1,0,0,0} it returns p[i] exactly, which is what makes the identity map equal the plain path. */
+static void affine3_fwd(const double *m, const double *p, double *o) {
+  for (int i = 0; i < 3; ++i) o[i] = fma(m[4 * i], p[0], fma(m[4 * i + 1], p[1], fma(m[4 * i + 2], p[2], m[4 * i + 3])));
 }
 
 long tsdf_oracle_aabb_aug(const float *depth, const int32_t *header, const tsdf_cam *cam, const double *xf,
@@ -283,7 +291,7 @@ long tsdf_oracle_aabb_aug(const float *depth, const int32_t *header, const tsdf_
       const double q = (double)d / cam->focal;
       const double p[3] = {q * ((double)(col + l) - cam->cx), -q * ((double)(row + t) - cam->cy), -(double)d};
       double o[3];
-      affine3(xf, p, o);
+      affine3_fwd(xf, p, o);
       for (int a = 0; a < 3; ++a) {
         const float v = (float)o[a];
         if (v < mn[a]) mn[a] = v;
@@ -325,7 +333,7 @@ void tsdf_oracle_voxels_aug(const float *depth, const int32_t *header, const flo
         const double q2 = (double)pd / F;
         const double w[3] = {((double)pix_x - cam->cx) * q2, -((double)pix_y - cam->cy) * q2, -(double)pd};
         double wp[3], ts[3];
-        affine3(fwd, w, wp);
+        affine3_fwd(fwd, w, wp);
         for (int a = 0; a < 3; ++a) ts[a] = fabs(vp[a] - wp[a]) / (double)trunc_dis;
         const double dist = sqrt(ts[0] * ts[0] + ts[1] * ts[1] + ts[2] * ts[2]);
         if (dist > 1.0) ts[0] = ts[1] = ts[2] = 1.0;
