@@ -781,7 +781,7 @@ __device__ __forceinline__ void lds_store(int *p, int v) {
 // Work queue: frames beyond the first one per group are handed out dynamically (frame cost varies
 // ~3x with the hand's size; a static 4-frames-per-CU split left a 25 % tail).  One slot per launch in
 // flight; `next` and `done` return to 0 when the launch's last group leaves, so a slot needs no reset.
-constexpr int kQueueSlots = 64;
+constexpr int kQueueSlots = 1024;  // launches that may be in flight at once (8 KiB of device memory)
 __device__ unsigned int g_queue[kQueueSlots][2];
 
 __device__ __forceinline__ void group_barrier(int *cnt, int &target) {

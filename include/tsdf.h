@@ -15,8 +15,8 @@
  *   - Calls enqueue work on `hip_stream` (a hipStream_t, NULL = default stream)
  *     and return WITHOUT synchronising.  They allocate nothing, never print and
  *     never throw; they are re-entrant for distinct streams and may be captured
- *     into a hipGraph.  (Each launch takes one of 64 device-side work-queue slots,
- *     chosen round-robin on the host and left clean by the launch itself: up to 64
+ *     into a hipGraph.  (Each launch takes one of 1024 device-side work-queue slots,
+ *     chosen round-robin on the host and left clean by the launch itself: up to 1024
  *     launches may be in flight at once, and one captured launch must not be
  *     replayed concurrently with itself.)
  *   - Return value: TSDF_OK (0) or a negative tsdf_status.  Per-frame data

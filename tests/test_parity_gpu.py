@@ -481,6 +481,26 @@ def test_concurrent_streams_and_graph_replay(pkg, synth):
     for tag, o in outs:
         ref = ref_a if tag == "a" else ref_b
         assert torch.equal(o.tsdf, ref.tsdf) and torch.equal(o.mid_p, ref.mid_p)
+    # many launches in flight on several streams, never synchronised in between (queue slots are per launch)
+    streams = [torch.cuda.Stream(d) for _ in range(6)]
+    small = 200
+    oa_s, ha_s = oa[: small + 1].contiguous(), ha[:small].contiguous()
+    ref_s = pkg.voxelize(da, oa_s, ha_s)
+    torch.cuda.synchronize()
+    ring = [[pkg.voxelize(da, oa_s, ha_s) for _ in range(3)] for _ in streams]
+    torch.cuda.synchronize()
+    for r in ring:
+        for o in r:
+            o.tsdf.zero_()
+    torch.cuda.synchronize()
+    for k in range(60):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                pkg.voxelize(da, oa_s, ha_s, out=ring[si][k % 3])
+    torch.cuda.synchronize()
+    for r in ring:
+        for o in r:
+            assert torch.equal(o.tsdf, ref_s.tsdf) and torch.equal(o.max_l, ref_s.max_l)
     # hipGraph capture + replay (the call allocates nothing and does not synchronise)
     out = pkg.voxelize(da, oa, ha)
     torch.cuda.synchronize()
