@@ -91,11 +91,19 @@ def summarize(out):
 def collect(out, tag):
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
+    # gpurun merges results into gpurun_out/ without deleting what earlier calls left there: take the trace
+    # files of the run the summary was computed from (its pid prefix), not whatever the glob finds last
+    summ = json.load(open(os.path.join(out, "summary.json")))
+    prefix = summ.get("kernel_trace", {}).get("file", "").split("_", 1)[0]
     for sub, pat in (("trace", "*_kernel_stats.csv"), ("trace", "*_domain_stats.csv")):
-        for f in glob.glob(os.path.join(out, sub, "**", pat), recursive=True):
+        for f in sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True), key=os.path.getmtime):
+            if prefix and not os.path.basename(f).startswith(prefix + "_"):
+                continue
             shutil.copy(f, os.path.join(dst, "bench_" + os.path.basename(f).split("_", 1)[1]))
     for sub in ("pmc_fetch", "pmc_write", "pmc_fetch_aabb", "pmc_sq"):
-        for f in glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True):
+        files = sorted(glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True),
+                       key=os.path.getmtime)
+        for f in files[-1:]:  # the newest run only (see above)
             rows = [r for r in csv.DictReader(open(f)) if "tsdf" in r["Kernel_Name"]]
             keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
                     "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
