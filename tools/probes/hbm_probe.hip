@@ -44,7 +44,7 @@ __global__ __launch_bounds__(1024) void k_mix(const f4 *__restrict__ a, f4 *__re
 // Volume-shaped writes: 512-thread groups each write whole 32^3 x 3 float volumes (393,216 B) either as one
 // contiguous stream or the way the voxel pass does (thread -> 4 x-voxels, z pairs, the 3 channel planes 128 KiB
 // apart written back to back).  Tells whether the [c][z][y][x] plane stride costs anything at the HBM.
-template <bool NT, bool PLANES>
+template <bool NT, bool PLANES, int ROT = 0>
 __global__ __launch_bounds__(1024) void k_volumes(f4 *__restrict__ out, int n_frames) {
   const int group = threadIdx.x >> 9, t = threadIdx.x & 511;
   const f4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(1024) void k_volumes(f4 *__restrict__ out, int n_fr
     f4 *o = out + (size_t)fr * (3 * 32768 / 4);
     if (PLANES) {
       const int gi = t & 255, s0 = t >> 8;           // (y, x4) and the z parity
-      for (int z = s0; z < 32; z += 2) {
+      for (int zz = s0; zz < 32; zz += 2) {
+        const int z = ROT ? (zz + fr * ROT) & 31 : zz;   // ROT: every frame starts at a different slice
         const int e4 = (z * 32 * 32 + gi * 4) / 4;   // float4 index inside a plane
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -110,6 +111,9 @@ int main(int argc, char **argv) {
     runv("contiguous nt", [&] { hipLaunchKernelGGL((k_volumes<true, false>), grid, 1024, 0, 0, b, nf); });
     runv("3 planes 128 KiB apart", [&] { hipLaunchKernelGGL((k_volumes<false, true>), grid, 1024, 0, 0, b, nf); });
     runv("3 planes 128 KiB apart nt", [&] { hipLaunchKernelGGL((k_volumes<true, true>), grid, 1024, 0, 0, b, nf); });
+    runv("planes nt, start slice rotated x5", [&] { hipLaunchKernelGGL((k_volumes<true, true, 5>), grid, 1024, 0, 0, b, nf); });
+    runv("planes nt, start slice rotated x2", [&] { hipLaunchKernelGGL((k_volumes<true, true, 2>), grid, 1024, 0, 0, b, nf); });
+    runv("planes, start slice rotated x5", [&] { hipLaunchKernelGGL((k_volumes<false, true, 5>), grid, 1024, 0, 0, b, nf); });
   }
   CK(hipDeviceSynchronize());
   printf("device: %s, %d CUs\n", p.name, p.multiProcessorCount);
