@@ -1097,40 +1097,6 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         const int sw4 = (sw + 3) & ~3;
         const bool staged = (int64_t)sw4 * sh <= kStageFloats;  // group-uniform
 
-        // ---- per-frame tables (true divisions; (x,z)/(y,z) pairs spread over the group) ----
-        const double vl = (double)g.voxel_len;
-        const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
-        TSDF_STAMP(kGroups * iter + group, 5);
-        if (vt < R) {
-          const double v_z = oz + (double)vt * vl;  // :28
-          ZEntry ze;
-          ze.q = -cam.focal / v_z;                    // :30
-          ze.vzs = v_z * vk.it;
-          ze.negthr = f32_round_up(-v_z);             // pd < -v_z  <=>  w_z > v_z  (:65)
-          ze.pad = 0.f;
-          ztab[vt] = ze;
-        }
-        if constexpr (AUG) {
-          // products of the inverse map, one per (axis, index, row): see phase2_aug
-          const double *inv = xforms + 24 * (int64_t)frame + 12;
-          for (int e = vt; e < 9 * R; e += kGW) {
-            const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
-            const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
-            atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
-          }
-        }
-        const bool use_tab = !AUG && R <= kTabR;  // uniform
-        if (use_tab) {
-          for (int e = vt; e < R * R; e += kGW) {
-            const int z = e / R, i = e - z * R;
-            const double q = -cam.focal / (oz + (double)z * vl);                              // :30
-            const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
-            pxtab[tab_index<LAYOUT>(i, z, R)] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);    // :31
-            pytab[tab_index<LAYOUT>(i, z, R)] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);   // :32
-          }
-        }
-        TSDF_STAMP(kGroups * iter + group, 6);
-
         // ---- stage the rectangle of valid pixels into LDS by LDS-DMA (global_load_lds_dwordx4) ----
         // No VGPR staging and no ds_write pass: each wave instruction moves up to 64 x 16 B straight into
         // the row-major LDS image (lane i lands at base + 16*i, so lanes are laid out as [row][4-pixel
@@ -1178,8 +1144,43 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
               }
             }
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is counted in vmcnt
         }
+        // ---- per-frame tables (true divisions; (x,z)/(y,z) pairs spread over the group) ----
+        const double vl = (double)g.voxel_len;
+        const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
+        TSDF_STAMP(kGroups * iter + group, 5);
+        if (vt < R) {
+          const double v_z = oz + (double)vt * vl;  // :28
+          ZEntry ze;
+          ze.q = -cam.focal / v_z;                    // :30
+          ze.vzs = v_z * vk.it;
+          ze.negthr = f32_round_up(-v_z);             // pd < -v_z  <=>  w_z > v_z  (:65)
+          ze.pad = 0.f;
+          ztab[vt] = ze;
+        }
+        if constexpr (AUG) {
+          // products of the inverse map, one per (axis, index, row): see phase2_aug
+          const double *inv = xforms + 24 * (int64_t)frame + 12;
+          for (int e = vt; e < 9 * R; e += kGW) {
+            const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
+            const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
+            atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
+          }
+        }
+        const bool use_tab = !AUG && R <= kTabR;  // uniform
+        if (use_tab) {
+          for (int e = vt; e < R * R; e += kGW) {
+            const int z = e / R, i = e - z * R;
+            const double q = -cam.focal / (oz + (double)z * vl);                              // :30
+            const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
+            pxtab[tab_index<LAYOUT>(i, z, R)] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);    // :31
+            pytab[tab_index<LAYOUT>(i, z, R)] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);   // :32
+          }
+        }
+        TSDF_STAMP(kGroups * iter + group, 6);
+
+        // the copy was issued before the tables were computed (worth 1.1 % of the launch, tools/ab_precise.py)
+        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is counted in vmcnt
         TSDF_STAMP(kGroups * iter + group, 7);
         if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
           if (gwave == 0 && lane == 0) ctl.hdr[group].pad = lds_load(&ctl.idle[group ^ 1]);
