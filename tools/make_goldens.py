@@ -137,4 +137,8 @@ def main():
 
 
 if __name__ == "__main__":
+    import argparse
+
+    argparse.ArgumentParser(description="Regenerate tests/golden/*.npz by running the reference's own code "
+                                        "(needs /root/reference; no options).").parse_args()
     main()
