@@ -73,6 +73,10 @@ def lib():
         L.tsdf_oracle_voxelize_aug.restype = ctypes.c_int
         L.tsdf_oracle_voxelize_aug.argtypes = [fp, lp, ip, ctypes.c_int, ctypes.c_int, cp, ctypes.c_int,
                                                ctypes.c_int, dp, fp, fp, fp, ip]
+        L.tsdf_oracle_normalize_joints.restype = None
+        L.tsdf_oracle_normalize_joints.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+        L.tsdf_oracle_transform_joints.restype = None
+        L.tsdf_oracle_transform_joints.argtypes = [fp, dp, ctypes.c_int, ctypes.c_int, fp]
         _lib = L
     return _lib
 
@@ -162,3 +166,27 @@ def voxelize_aug(depth, offsets, headers, xforms, R=32, layout=0, n_threads=1):
         layout, n_threads, _p(xforms, ctypes.c_double), _p(out, ctypes.c_float), _p(max_l, ctypes.c_float),
         _p(mid_p, ctypes.c_float), _p(status, ctypes.c_int32))
     return dict(tsdf=out, max_l=max_l, mid_p=mid_p, status=status)
+
+
+def normalize_joints(gt, max_l, mid_p, clamp=True):
+    """pre/joint_nor.py:8-18 + clamp (3D_CNN/train.py:241-242); gt float32[n,3J] -> same shape."""
+    gt = np.ascontiguousarray(gt, dtype=np.float32)
+    n = gt.shape[0]
+    J = gt.reshape(n, -1).shape[1] // 3
+    max_l = np.ascontiguousarray(max_l, dtype=np.float32).reshape(n)
+    mid_p = np.ascontiguousarray(mid_p, dtype=np.float32).reshape(n, 3)
+    out = np.empty_like(gt)
+    lib().tsdf_oracle_normalize_joints(_p(gt, ctypes.c_float), _p(max_l, ctypes.c_float), _p(mid_p, ctypes.c_float),
+                                       n, J, 1 if clamp else 0, _p(out, ctypes.c_float))
+    return out
+
+
+def transform_joints(gt, xforms):
+    """T(joint) with each frame's forward map (augmented labels), float32 result of gt's shape."""
+    gt = np.ascontiguousarray(gt, dtype=np.float32)
+    n = gt.shape[0]
+    J = gt.reshape(n, -1).shape[1] // 3
+    xforms = np.ascontiguousarray(xforms, dtype=np.float64).reshape(n, 24)
+    out = np.empty_like(gt)
+    lib().tsdf_oracle_transform_joints(_p(gt, ctypes.c_float), _p(xforms, ctypes.c_double), n, J, _p(out, ctypes.c_float))
+    return out

@@ -69,7 +69,7 @@ long tsdf_oracle_aabb(const float *depth, const int32_t *header, const tsdf_cam 
       const int x = col + l;          /* pos % b_w + l   :84 */
       const int y = row + t;          /* pos // b_w + t  :85 (integer division, App. B#3) */
       const float d = depth[pos];     /* :86 */
-      if (fabsf(d) < cam->invalid_eps) continue; /* :87 */
+      if (!(fabsf(d) >= cam->invalid_eps)) continue; /* :87; NaN is invalid (include/tsdf.h) */
       const double q = (double)d / cam->focal;                 /* :91 */
       const float cxp = (float)(q * ((double)x - cam->cx));    /* :92, rounded by the f32 smem store :95 */
       const float cyp = (float)(-q * ((double)y - cam->cy));   /* :93 */
@@ -150,7 +150,7 @@ void tsdf_oracle_voxels(const float *depth, const int32_t *header, const float *
         }
         const int32_t idx = (pix_y - t) * bw + pix_x - l;                  /* :38 */
         const float pd = depth[idx];                                       /* :39 */
-        if (fabsf(pd) < cam->invalid_eps) {                                /* :40 */
+        if (!(fabsf(pd) >= cam->invalid_eps)) {                            /* :40; NaN is invalid */
           if (pixmap) pixmap[vi] = -2 - idx;
           continue;
         }
@@ -182,6 +182,19 @@ void tsdf_oracle_voxels(const float *depth, const int32_t *header, const float *
   }
 }
 
+/* Degenerate-frame rule of include/tsdf.h applied to a placed grid: the extent must be positive and finite
+ * and the centre finite (a +-inf depth passes |d| >= eps and poisons the AABB).  Returns the status and
+ * clears what the header says is cleared. */
+static int grid_status(float *grid) {
+  const int ext_ok = grid[3] > 0.0f && isfinite(grid[3]);
+  const int mid_ok = isfinite(grid[0]) && isfinite(grid[1]) && isfinite(grid[2]);
+  if (ext_ok && mid_ok) return TSDF_FRAME_OK;
+  grid[3] = grid[4] = grid[5] = 0.0f;
+  /* a zero extent keeps its (finite) centre; a non-finite centre is reported as 0 */
+  if (!mid_ok) grid[0] = grid[1] = grid[2] = 0.0f;
+  return TSDF_FRAME_DEGENERATE;
+}
+
 /* One frame end to end: cal_tsdf_cuda (pre/tsdf_numba.py:119-161) with the
  * degenerate-frame convention of include/tsdf.h.  Returns the frame status. */
 static int oracle_frame(const float *depth, int64_t n_elem, const int32_t *header, int R,
@@ -199,10 +212,7 @@ static int oracle_frame(const float *depth, int64_t n_elem, const int32_t *heade
       status = TSDF_FRAME_DEGENERATE;
     } else {
       tsdf_oracle_glue(mn, mx, R, cam, grid, ori);
-      if (!(grid[3] > 0.0f) || !isfinite(grid[3])) {
-        status = TSDF_FRAME_DEGENERATE;
-        grid[3] = grid[4] = grid[5] = 0.0f;
-      }
+      status = grid_status(grid);
     }
   }
   if (status == TSDF_FRAME_OK) {
@@ -287,7 +297,7 @@ long tsdf_oracle_aabb_aug(const float *depth, const int32_t *header, const tsdf_
   for (int row = 0; row < bh; ++row)
     for (int col = 0; col < bw; ++col) {
       const float d = depth[(long)row * bw + col];
-      if (fabsf(d) < cam->invalid_eps) continue;
+      if (!(fabsf(d) >= cam->invalid_eps)) continue;
       const double q = (double)d / cam->focal;
       const double p[3] = {q * ((double)(col + l) - cam->cx), -q * ((double)(row + t) - cam->cy), -(double)d};
       double o[3];
@@ -329,7 +339,7 @@ void tsdf_oracle_voxels_aug(const float *depth, const int32_t *header, const flo
         const int32_t pix_y = trunc_i32((-v[1] * q) + cam->cy);
         if (pix_x < l || pix_x >= r || pix_y < t || pix_y >= b) continue;
         const float pd = depth[(pix_y - t) * bw + pix_x - l];
-        if (fabsf(pd) < cam->invalid_eps) continue;
+        if (!(fabsf(pd) >= cam->invalid_eps)) continue;
         const double q2 = (double)pd / F;
         const double w[3] = {((double)pix_x - cam->cx) * q2, -((double)pix_y - cam->cy) * q2, -(double)pd};
         double wp[3], ts[3];
@@ -372,10 +382,7 @@ int tsdf_oracle_voxelize_aug(const float *depth, const int64_t *offsets, const i
       status = TSDF_FRAME_DEGENERATE;
     } else {
       tsdf_oracle_glue(mn, mx, R, cam, grid, ori);
-      if (!(grid[3] > 0.0f) || !isfinite(grid[3])) {
-        status = TSDF_FRAME_DEGENERATE;
-        grid[3] = grid[4] = grid[5] = 0.0f;
-      }
+      status = grid_status(grid);
     }
     if (out_tsdf) {
       if (status == TSDF_FRAME_OK)
@@ -388,4 +395,42 @@ int tsdf_oracle_voxelize_aug(const float *depth, const int64_t *offsets, const i
     if (out_status) out_status[i] = status;
   }
   return n_threads;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Label normalisation — pre/joint_nor.py:8-18 and the per-sample loop of 3D_CNN/train.py:236-244:
+ *   joint_nor = (joint - mid_p) / max_l + 0.5      float32, three separately rounded operations
+ *   joint_nor[joint_nor < 0] = 0 ; joint_nor[joint_nor > 1] = 1      (train.py:241-242; NaN stays NaN)
+ * gt float32[n][3*J] (x,y,z per joint), out the same shape.  A frame whose status is not OK (max_l == 0;
+ * the reference returns None for it, tsdf_numba.py:162-171) gets 0.5 everywhere — the cube centre —
+ * instead of the reference's division by zero (include/tsdf.h).
+ */
+void tsdf_oracle_normalize_joints(const float *gt, const float *max_l, const float *mid_p, int n, int J,
+                                  int clamp, float *out) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < 3 * J; ++j) {
+      const size_t e = (size_t)i * 3 * J + j;
+      if (!(max_l[i] > 0.0f)) { out[e] = 0.5f; continue; }
+      volatile float a = gt[e] - mid_p[3 * (size_t)i + j % 3];
+      volatile float b = a / max_l[i];
+      float v = b + 0.5f;
+      if (clamp) {
+        if (v < 0.0f) v = 0.0f;
+        if (v > 1.0f) v = 1.0f;
+      }
+      out[e] = v;
+    }
+}
+
+/* Augmented labels (pre/process.py:232-249 maps the joints with the cloud's own S and R): T(joint) with the
+ * forward map of the frame's xform, fused chain in float64 (affine3_fwd), rounded to float32. */
+void tsdf_oracle_transform_joints(const float *gt, const double *xforms, int n, int J, float *out) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < J; ++j) {
+      const float *g = gt + ((size_t)i * J + j) * 3;
+      const double p[3] = {(double)g[0], (double)g[1], (double)g[2]};
+      double o[3];
+      affine3_fwd(xforms + 24 * (size_t)i, p, o);
+      for (int a = 0; a < 3; ++a) out[((size_t)i * J + j) * 3 + a] = (float)o[a];
+    }
 }

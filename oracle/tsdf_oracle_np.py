@@ -23,7 +23,7 @@ def aabb(depth, header):
     l, t, r, b = (int(v) for v in header[2:6])
     bw, bh = r - l, b - t
     d = np.asarray(depth, dtype=np.float32).reshape(bh, bw)
-    valid = ~(np.abs(d) < np.float32(1))  # :87
+    valid = np.abs(d) >= np.float32(1)  # :87 (NaN is invalid: include/tsdf.h)
     if not valid.any():
         return 0, None, None
     x = (np.arange(bw, dtype=np.int64) + l)[None, :]  # :84
@@ -74,7 +74,7 @@ def voxels(depth, header, ori, voxel_len, trunc_dis, R=32):
         inb = (pix_x >= l) & (pix_x < r) & (pix_y >= t) & (pix_y < b)  # :36
         gidx = np.where(inb, (pix_y - t) * bw + pix_x - l, 0)  # :38
         pd = depth[gidx]  # :39
-        ok = inb & ~(np.abs(pd) < np.float32(1))  # :40
+        ok = inb & (np.abs(pd) >= np.float32(1))  # :40 (NaN is invalid)
         pd64 = pd.astype(np.float64)
         q2 = pd64 / FOCAL  # :43
         w_x = (pix_x - CENTER_X) * q2  # :44
@@ -101,7 +101,23 @@ def frame(depth, header, R=32):
     if nv == 0:
         return np.zeros((3, R, R, R), np.float32), np.float32(0), np.zeros(3, np.float32)
     mid_p, max_l, vl, tr, ori = glue(mn, mx, R)
-    if not (max_l > 0):
-        return np.zeros((3, R, R, R), np.float32), np.float32(0), mid_p
+    if not (max_l > 0 and np.isfinite(max_l)) or not np.isfinite(mid_p).all():
+        return np.zeros((3, R, R, R), np.float32), np.float32(0), (mid_p if np.isfinite(mid_p).all() else np.zeros(3, np.float32))
     out, _ = voxels(depth, header, ori, vl, tr, R)
     return out, max_l, mid_p
+
+
+def normalize_joints(gt, max_l, mid_p, clamp=True):
+    """pre/joint_nor.py:8-18 + the clamp of 3D_CNN/train.py:241-242, float32; degenerate frames -> 0.5."""
+    gt = np.asarray(gt, np.float32)
+    n = gt.shape[0]
+    j = gt.reshape(n, -1, 3)
+    max_l = np.asarray(max_l, np.float32).reshape(n)
+    mid_p = np.asarray(mid_p, np.float32).reshape(n, 3)
+    with np.errstate(all="ignore"):
+        out = (j - mid_p[:, None, :]) / max_l[:, None, None] + np.float32(0.5)
+    if clamp:
+        out = np.where(out < 0, np.float32(0), out)
+        out = np.where(out > 1, np.float32(1), out)
+    out = np.where((max_l > 0)[:, None, None], out, np.float32(0.5)).astype(np.float32)
+    return out.reshape(gt.shape)

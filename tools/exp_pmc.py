@@ -11,9 +11,21 @@ depth, off, hdr = synth.synth_batch(1024, "full", seed0=0)
 td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
 out = pkg.voxelize(td, to, th)
 mode = os.environ.get("PMC_MODE", "aabb")
-for _ in range(6):
-    if mode == "aabb":
-        pkg.aabb(td, to, th)
-    else:
+if mode.startswith("aug"):       # aug32 / aug64: the fused-augmentation kernel (BASELINE configs[4] at aug64)
+    R = int(mode[3:] or 64)
+    xf = torch.from_numpy(pkg.augment.random_affines(out.mid_p.cpu().numpy(), rng=1)[0]).to(dev)
+    oa = pkg.voxelize_aug(td, to, th, xf, res=R)
+    for _ in range(6):
+        pkg.voxelize_aug(td, to, th, xf, res=R, out=oa)
+elif mode == "crop":             # 1024 MSRA-like crops
+    depth, off, hdr = synth.synth_batch(1024, "crop", seed0=0)
+    td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
+    for _ in range(6):
         pkg.voxelize(td, to, th, out=out)
+else:
+    for _ in range(6):
+        if mode == "aabb":
+            pkg.aabb(td, to, th)
+        else:
+            pkg.voxelize(td, to, th, out=out)
 torch.cuda.synchronize()
