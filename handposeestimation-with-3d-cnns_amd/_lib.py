@@ -39,6 +39,20 @@ class TsdfCam(ctypes.Structure):
     ]
 
 
+class TsdfLabels(ctypes.Structure):
+    """``tsdf_labels`` of include/tsdf.h: device pointers for the fused label normalisation."""
+
+    _fields_ = [
+        ("d_gt", ctypes.c_void_p),
+        ("n_joints", ctypes.c_int),
+        ("clamp", ctypes.c_int),
+        ("d_out_gt_nor", ctypes.c_void_p),
+        ("d_out_gt_aug", ctypes.c_void_p),
+    ]
+
+
+ABI_VERSION = 3
+
 _lib = None
 
 
@@ -74,6 +88,22 @@ def load():
                                         vp, vp, vp, vp, vp]
     L.tsdf_aabb_hip.restype = ctypes.c_int
     L.tsdf_aabb_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, vp, vp, vp, vp, vp]
+    lab_p = ctypes.POINTER(TsdfLabels)
+    L.tsdf_voxelize_labels_hip.restype = ctypes.c_int
+    L.tsdf_voxelize_labels_hip.argtypes = L.tsdf_voxelize_hip.argtypes + [lab_p]
+    L.tsdf_voxelize_aug_labels_hip.restype = ctypes.c_int
+    L.tsdf_voxelize_aug_labels_hip.argtypes = L.tsdf_voxelize_aug_hip.argtypes + [lab_p]
+    L.tsdf_normalize_joints_hip.restype = ctypes.c_int
+    L.tsdf_normalize_joints_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    L.tsdf_denormalize_joints_hip.restype = ctypes.c_int
+    L.tsdf_denormalize_joints_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+    L.tsdf_debug_pixmap_hip.restype = ctypes.c_int
+    L.tsdf_debug_pixmap_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
+                                        vp, vp, vp, vp]
+    L.tsdf_stream_release.restype = ctypes.c_int
+    L.tsdf_stream_release.argtypes = [vp]
+    if L.tsdf_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.tsdf_version()}, this package needs {ABI_VERSION}: rebuild it")
     _lib = L
     return L
 

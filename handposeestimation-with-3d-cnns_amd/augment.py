@@ -42,18 +42,56 @@ def rotation_xyz(rx_deg, ry_deg, rz_deg) -> np.ndarray:
     return Rx @ Ry @ Rz
 
 
+def reference_draw(rs: "np.random.RandomState"):
+    """The three draws of one ``data_aug`` call, in the reference's order and with its calls
+    (pre/process.py:209, 215, 216): ``uniform(2/3, 3/2)``, ``randint(-30, 30)``, ``randint(-30, 30)`` on numpy's
+    legacy generator (``np.random.seed(k)`` + module functions == ``RandomState(k)`` methods).
+    Returns (stretch_xy, rot_xy, rot_z) — the last one is drawn by the reference but never used."""
+    stretch = rs.uniform(2 / 3, 3 / 2)
+    rot_xy = rs.randint(-30, 30)
+    rot_z = rs.randint(-30, 30)
+    return float(stretch), int(rot_xy), int(rot_z)
+
+
+def reference_matrices(stretch_xy: float, rot_xy: int):
+    """``S`` and ``R`` exactly as ``data_aug`` builds them (pre/process.py:210-224): S = diag(s, s, 1),
+    R = Rx(t)·Ry(t)·Rz(t) with t = rot_xy degrees — R_z reuses the x/y angle (SURVEY.md App. B#8)."""
+    S = np.diag(np.array([stretch_xy, stretch_xy, 1.0]))
+    R = rotation_xyz(rot_xy, rot_xy, rot_xy)
+    return S, R
+
+
+def reference_data_aug(points: np.ndarray, S: np.ndarray, R: np.ndarray) -> np.ndarray:
+    """The reference's point mapping as written (pre/process.py:251-259 for the cloud, :237-249 for the joints):
+    ``(p·S - m)·R + m`` in row-vector form, where the "centre" m repeats the mean of the point's OWN three
+    stretched coordinates (``np.mean(..., axis=2)``) — the defect ``random_affines`` fixes by using a real
+    centre.  points [..., 3]; used by the tests that pin this module's conventions to the reference's output."""
+    p = np.asarray(points, np.float64)
+    ps = p @ S
+    m = ps.mean(axis=-1, keepdims=True)
+    return (ps - m) @ R + m
+
+
 def random_affines(centres: np.ndarray, rng=None):
     """One augmentation per frame with the reference's distributions (pre/process.py:209-216).
 
     centres  [n,3]  the point each frame is stretched/rotated about (use the un-augmented ``mid_p``).
+    rng      seed / ``np.random.Generator``; or a legacy ``np.random.RandomState``, in which case every frame
+             takes the reference's own three draws in its order (:func:`reference_draw`).
     Returns (xforms float64[n,24], params dict(stretch, rot_xy, rot_z)).
     """
-    rng = np.random.default_rng(rng)
     m = np.asarray(centres, np.float64).reshape(-1, 3)
     n = m.shape[0]
-    stretch = rng.uniform(2 / 3, 3 / 2, n)
-    rot_xy = rng.integers(-30, 30, n)
-    rot_z = rng.integers(-30, 30, n)
+    if isinstance(rng, np.random.RandomState):
+        draws = [reference_draw(rng) for _ in range(n)]
+        stretch = np.array([d[0] for d in draws], np.float64)
+        rot_xy = np.array([d[1] for d in draws], np.int64)
+        rot_z = np.array([d[2] for d in draws], np.int64)
+    else:
+        rng = np.random.default_rng(rng)
+        stretch = rng.uniform(2 / 3, 3 / 2, n)
+        rot_xy = rng.integers(-30, 30, n)
+        rot_z = rng.integers(-30, 30, n)
     S = np.zeros((n, 3, 3))
     S[:, 0, 0] = stretch
     S[:, 1, 1] = stretch

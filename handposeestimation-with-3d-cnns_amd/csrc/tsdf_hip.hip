@@ -5,34 +5,40 @@
 //   phase 1  min_max_kernel  (pre/tsdf_numba.py:75-116,140-141)  AABB of all valid pixels
 //   glue     host numpy      (pre/tsdf_numba.py:142-147)          grid placement, float32
 //   phase 2  tsdf_kernel     (pre/tsdf_numba.py:15-72)            per-voxel project/gather/TSDF
+//   labels   joint_nor       (pre/joint_nor.py:8-18, 3D_CNN/train.py:236-244)  optional, same launch
 // Arithmetic contract: SURVEY.md Appendix A (float32 parameters, float64 intermediates,
 // unfused multiply-then-add for the pixel index, float32 store).
 //
 // Design (DESIGN.md has the numbers):
 //   * one persistent launch; one 1024-thread workgroup (16 wave64) per CU, which owns the CU's LDS.
 //     Its two 512-thread halves ("groups") each process whole frames — the first one positional, the
-//     rest from an atomic work queue — and take turns on the single 128 KiB LDS stage, so one group's
-//     row streaming overlaps the other group's voxel arithmetic and stores.  Groups synchronise on LDS
+//     rest from a work queue — independently of each other: one group's row streaming (memory-bound)
+//     overlaps the other group's voxel arithmetic and stores on the same CU.  Groups synchronise on LDS
 //     counters (s_barrier would span both).  The AABB and the grid placement never leave the chip;
-//   * phase 1 streams the crop once with 16-byte loads, lane <-> 4 consecutive columns, wave <-> rows,
+//   * phase 1 streams the crop ONCE with vector loads, lane <-> P consecutive columns, wave <-> rows,
 //     two register buffers in ping-pong behind counted vmcnt waits.  It does NOT back-project every
 //     pixel (one float64 division each): f32(f64(d)/F * (x-cx)) is monotone in d for a fixed column x
 //     (and likewise per row), so the AABB is the extreme of the formula applied to each column's /
 //     row's (min,max) valid depth — bit-identical result, 2(b_w+b_h) evaluations per wave instead of
-//     b_w*b_h; d/F uses Markstein's correction (exact quotient in 3 ops).  The same pass yields the pixel
-//     rectangle that holds every valid pixel;
-//   * staging: that rectangle (the only pixels phase 2 can ever use — everything outside it is
-//     rejected by pre/tsdf_numba.py:36 or :40) is copied into LDS by LDS-DMA (global_load_lds_dwordx4),
-//     so the per-voxel gather is an LDS read: no vector-memory latency, and stores never block loads;
-//     a rectangle over 32 Ki pixels falls back to gathering from global memory (L2);
+//     b_w*b_h; d/F uses Markstein's correction (exact quotient in 3 ops);
+//   * row-span capture: while a row is in registers, its span [first valid pixel, last valid pixel] —
+//     the only pixels of that row phase 2 can ever use; everything outside is rejected by
+//     pre/tsdf_numba.py:40 — is written to an LDS pool (one packed LDS atomic per row allocates it;
+//     the two groups allocate from opposite ends) and a per-row entry {offset, first, count} goes into
+//     the group's row table.  Depth is therefore read from HBM exactly once and the per-voxel gather is
+//     an LDS read.  A frame whose spans do not fit next to the other group's (or whose bbox is wider
+//     than 320 / taller than 256) gathers from global memory (L2) instead;
 //   * phase 2: pix_x depends on (x,z) only and pix_y on (y,z) only -> both tabulated per frame in LDS
-//     (true division for q = -F/v_z, unfused multiply-add, v_cvt_i32_f64 truncation).  Each lane owns 4
-//     consecutive voxels along the layout's fastest axis, so every wave store is 1 KiB contiguous
-//     (global_store_dwordx4 nt: the volume is written once; non-temporal stores keep the streamed depth
-//     rows cached for the staging copy).  The per-voxel chain uses reciprocals (<= a few ulp64 from the
-//     divisions it replaces — 10 orders of magnitude inside the 1e-5 parity bound); a wave whose 256
-//     voxels are all rejected or farther than the truncation distance along z skips the x/y terms (the
-//     result is then (+-1,+-1,+-1) or 0 by pre/tsdf_numba.py:54-57);
+//     (true division for q = -F/v_z, unfused multiply-add, v_cvt_i32_f64 truncation); the y table holds
+//     the row's pool entry directly.  Each lane owns 4 consecutive voxels along the layout's fastest
+//     axis, so every wave store is 1 KiB contiguous (global_store_dwordx4 nt: written once, never
+//     re-read).  The per-voxel chain uses reciprocals (<= a few ulp64 from the divisions it replaces —
+//     10 orders of magnitude inside the 1e-5 parity bound); a wave whose 256 voxels are all rejected or
+//     farther than the truncation distance along z skips the x/y terms (the result is then
+//     (+-1,+-1,+-1) or 0 by pre/tsdf_numba.py:54-57);
+//   * small batches (n <= CUs/2) take the split kernel instead: S workgroups per frame, each streams
+//     the frame (16 waves, L2 hits after the first) and voxelizes 1/S of the slow axis — no
+//     inter-workgroup communication, bit-identical results;
 //   * the augmented form (template AUG) maps every valid pixel / voxel centre / surface point through a
 //     per-frame affine transform instead (tsdf_voxelize_aug_hip, re-specified: see include/tsdf.h).
 // HBM-bound streaming read + streaming write.  No MFMA (gather/scatter, not a contraction), no
@@ -43,6 +49,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 
 #include "../../include/tsdf.h"
@@ -57,9 +65,11 @@ constexpr int kGroups = TSDF_GROUPS;    // half-workgroups: each walks its own f
 constexpr int kGW = kWG / kGroups;      // threads per group
 constexpr int kGWaves = kGW / 64;       // waves per group
 constexpr int kMaxR = 128;
-constexpr int kStageFloats = 32 * 1024; // 128 KiB depth stage in LDS (>= 181 x 181 pixels)
-constexpr int kTabR = 32;               // projection tables for R <= kTabR (2 x 4 KiB)
+constexpr int kTabR = 32;               // projection tables for R <= kTabR (2 + 4 KiB per group)
 constexpr int kRedStride = 12;
+constexpr int kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU; the workgroup takes all of it
+constexpr int kMaxRows = 256;           // rows per frame the row table holds (MSRA: 240)
+constexpr int kMaxCapW = 320;           // widest bounding box whose rows are captured (= one row pass)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-B access
@@ -253,14 +263,49 @@ struct Aabb {
 //   [0..4] minima: cam x, cam y, depth, valid column index, valid row index   [5..9] the maxima
 constexpr int kExt = 10;
 
+
+// ---- row-span capture -------------------------------------------------------------------------
+// While phase 1 has a row in registers it copies the row's span [first valid pixel, last valid pixel]
+// into an LDS pool and records where: one 32-bit entry per bbox row,
+//     bits 31..18  offset in the pool, in units of 4 floats
+//     bits 17..9   bbox-relative column of the first captured pixel
+//     bits  8..0   number of captured pixels (0: the row has no valid pixel)
+// A pixel (col, row) is then  pool[4*off4 + col - first]  when  0 <= col - first < cnt, and rejected by
+// pre/tsdf_numba.py:40 otherwise (every pixel outside the span is invalid by construction).
+// Every wave of the workgroup owns a fixed 1/16 of the pool and fills it with a bump pointer it keeps in a
+// scalar register: allocation costs no LDS round trip (an LDS atomic with return was tried first and cost
+// 3-7 us per frame: its latency is the LDS queue, which the other group's voxel pass keeps full).  Rows are
+// dealt to the waves round-robin, so the waves of a frame fill up evenly.  A row that does not fit makes the
+// frame "not captured": its voxel pass gathers from global memory instead (never wrong, only slower).
+// (LDS pointers carry their address space in the type: through generic pointers every access would be a
+// FLAT instruction, counted in vmcnt together with the row loads.)
+typedef __attribute__((address_space(3))) float *LdsF;
+typedef __attribute__((address_space(3))) unsigned *LdsU;
+typedef __attribute__((address_space(3))) int *LdsI;
+
+struct Capture {
+  LdsF pool;           // the pool
+  LdsU rowtab;         // this group's row table
+  LdsI fail;           // set when a row of this frame did not fit
+  int base4;           // this WAVE's private region of the pool: first unit (of 4 floats) ...
+  int cap4;            // ... and size in units
+  bool on;             // wave-uniform: capture this frame at all
+};
+
+constexpr unsigned kRowEmpty = (511u << 9);  // a row inside the bounding box without a valid pixel (cnt = 0);
+                                             // 0 is kept for "no such row" (outside the bounding box)
+__device__ __forceinline__ unsigned row_pack(int off4, int first, int cnt) {
+  return ((unsigned)off4 << 18) | ((unsigned)first << 9) | (unsigned)cnt;
+}
+
 // ---- phase 1: extents of all valid back-projected pixels of rows [rbeg, rend) ----------------
 // NW waves cooperate (row = rbeg + wave + NW*i); the result is wave-uniform in every thread.
 // `wave` is the (scalar) index of this wave among the NW cooperating waves, `sync` their barrier.
 // AUG: the extents are those of the affinely mapped cloud p' = A p + b (xf = 12 doubles), which needs
 // every valid pixel transformed (the monotone shortcut does not survive a rotation).
-template <int NW, bool AUG, typename SYNC>
+template <int NW, bool AUG, bool CAP, typename SYNC>
 __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, int rbeg, int rend, float *red,
-                                               float (&fin)[kExt], const int wave, SYNC sync,
+                                               float (&fin)[kExt], const int wave, SYNC sync, const Capture &cap,
                                                int stamp_iter = 0, const double *xf = nullptr) {
   (void)stamp_iter;
   constexpr int kWaves = NW;
@@ -271,6 +316,7 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
   // per-wave stash of reduced row extremes: lane i keeps the i-th non-empty row piece
   float s_rmin = TSDF_INF, s_rmax = -TSDF_INF;
   int s_row = 0, cnt = 0;
+  int cap_used = 0;  // units of this wave's pool region taken by the frame so far (scalar)
 
   auto flush_rows = [&]() {
     if (s_rmin <= s_rmax) {
@@ -327,18 +373,29 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
 
     auto reduce_rows = [&](int row0, const PixN<P> (&v)[kU]) {
       if (cnt > 64 - kU) flush_rows();  // wave-uniform (cnt is)
+      // ---- pass 1: which lanes of each row hold a pixel with |d| >= eps; ONE pool allocation for the kU rows.
+      // (Columns past the row end are not masked here: such a lane holds pixels of the next row, or a reload
+      // of this row's last pixels — either can only widen the captured window up to the row end, or make an
+      // empty row look occupied; pass 2 applies the exact per-pixel rule.) ----
+      unsigned long long vm[kU];       // 0: nothing to do for the row
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int row = row0 + kWaves * u;
-        bool ok[P];
-        bool any_ok = false;
+        float amax = __builtin_fabsf(v[u].d[0]);
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-          ok[j] = (__builtin_fabsf(v[u].d[j]) >= k.eps) & mine[j];  // pre/tsdf_numba.py:87 (NaN -> invalid)
-          any_ok |= ok[j];
-        }
-        // most row segments hold no valid pixel at all: skip them wave-wide
-        if (row < rend && __any(any_ok)) {
+        for (int j = 1; j < P; ++j) amax = vmax(amax, __builtin_fabsf(v[u].d[j]));  // NaN operands are dropped
+        // most row segments hold no valid pixel at all: they are skipped wave-wide (rows past the band are
+        // clamped duplicates of its last row)
+        vm[u] = row < rend ? __ballot(amax >= k.eps) : 0ull;                          // pre/tsdf_numba.py:87
+      }
+      // ---- pass 2: the extents ----
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int row = row0 + kWaves * u;
+        if (vm[u]) {
+          bool ok[P];
+#pragma unroll
+          for (int j = 0; j < P; ++j) ok[j] = (__builtin_fabsf(v[u].d[j]) >= k.eps) & mine[j];  // :87 (NaN -> invalid)
           if constexpr (AUG) {
             const double ym = (double)(f.t + row) - k.cy;
 #pragma unroll
@@ -376,6 +433,12 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
               rmin = vmin(rmin, lo);
               rmax = vmax(rmax, hi);
             }
+#ifdef TSDF_EXP_NOREDUCE
+            // (timing experiment only: WRONG y extent) no cross-lane work per row
+            s_rmin = vmin(s_rmin, rmin);
+            s_rmax = vmax(s_rmax, rmax);
+            s_row = row;
+#else
             const float wmin = wave_min(rmin), wmax = wave_max(rmax);
             if (lane == cnt) {
               s_rmin = wmin;
@@ -383,7 +446,37 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
               s_row = row;
             }
             ++cnt;
+#endif
           }
+        }
+      }
+      // ---- pass 3: copy the lane windows lf..ll of every occupied row into the pool (a handful of LDS stores
+      // under one exec mask) and post the rows' entries ----
+      if (CAP && cap.on) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int row = row0 + kWaves * u;
+          if (row >= rend) continue;  // scalar
+          unsigned ent = kRowEmpty;
+          if (vm[u]) {
+            const int lf = __builtin_ctzll(vm[u]), ll = 63 - __builtin_clzll(vm[u]);  // scalar
+            const int need = (P * (ll - lf + 1) + 3) >> 2;
+            if (cap_used + need <= cap.cap4) {
+              const int off4 = cap.base4 + cap_used;
+              cap_used += need;
+              const int first = P * lf;
+              const int endc = P * (ll + 1) < f.bw ? P * (ll + 1) : f.bw;  // a window crossing the row end is cut
+              const LdsF dst = cap.pool + (4 * off4 + P * (lane - lf));
+              if ((unsigned)(lane - lf) <= (unsigned)(ll - lf)) {
+#pragma unroll
+                for (int j = 0; j < P; ++j) dst[j] = v[u].d[j];
+              }
+              ent = row_pack(off4, first, endc - first);
+            } else if (lane == 0) {
+              *cap.fail = 1;
+            }
+          }
+          if (lane == 0) cap.rowtab[row] = ent;
         }
       }
     };
@@ -500,22 +593,27 @@ struct VoxK {
   double kq;   // (1/F) * it
   double ncx;  // -cx
   float eps;
-  int px0, py0;  // image coordinates of the first pixel of the rectangle holding every valid pixel
-  int dx, dy;    // its extent - 1 (inclusive upper bounds of rectangle-relative coordinates)
-  int stride;    // gather source: elements per row ...
-  int base;      // ... and index of the rectangle's first pixel
+  // Pixel coordinates are kept relative to a frame of reference (px0, py0): the bounding box when the
+  // voxel pass gathers from the LDS pool, the rectangle holding every valid pixel when it gathers from
+  // global memory (everything outside that rectangle is rejected by pre/tsdf_numba.py:36 or :40).
+  int px0, py0;  // image coordinates of that frame's first pixel
+  int dx, dy;    // its extent - 1 (inclusive upper bounds of relative coordinates)
+  int stride;    // global gather: elements per row of the crop ...
+  int base;      // ... and index of the frame of reference's first pixel in it
 };
 
-__device__ __forceinline__ void zero_volume(float *__restrict__ out, int R, int gtid) {
+__device__ __forceinline__ void zero_volume(float *__restrict__ out, int R, int tid, int T, int part, int parts) {
   const int n4 = 3 * R * R * R / 4;
+  const int per = (n4 + parts - 1) / parts;
+  const int beg = part * per, end = beg + per < n4 ? beg + per : n4;
   f4 *o4 = reinterpret_cast<f4 *>(out);
   const f4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int i = gtid; i < n4; i += kGW) o4[i] = z;
+  for (int i = beg + tid; i < end; i += T) o4[i] = z;
 }
 
 // Projection of a voxel coordinate onto a pixel coordinate, pre/tsdf_numba.py:30-32:
 //   pix = int(v * q + c)  with q = -F / v_z   (multiply, round, add, round, truncate)
-// returned relative to the valid-pixel rectangle, or -1 when outside it (then :36 or :40 rejects).
+// returned relative to p0, or -1 when outside [p0, p0 + dmax] (then :36 or :40 rejects).
 __device__ __forceinline__ int project_rel(double v, double q, double c, int p0, int dmax) {
   const int rel = trunc_i32(mul_then_add(v, q, c)) - p0;
   return (unsigned)rel <= (unsigned)dmax ? rel : -1;
@@ -528,39 +626,63 @@ __device__ __forceinline__ float f32_round_up(double t) {
   return f;
 }
 
-// Per-voxel value, pre/tsdf_numba.py:36-68, for the 4 voxels of one lane.  Coordinates are pre-scaled
-// by it = 1/trunc_dis:  tx = v_x*it - (pix_x-cx)*(pd*kq),  ty likewise,  tz = v_z*it + pd*it (w_z = -pd).
-//   ex[j], ry[j]          rectangle-relative pixel of voxel j (or -1: rejected)
-//   vxs[j], vys, vzs[j]   pre-scaled voxel centre;   negthr[j] = f32_round_up(-v_z)
-// The gather source is either the LDS stage or (rectangles too large for it) the frame in global memory.
-// It is passed with its address space in the type: a generic pointer would make every gather a FLAT load,
+// The gather source is either the LDS pool of captured row spans or the frame in global memory.  It is
+// passed with its address space in the type: a generic pointer would make every gather a FLAT load,
 // which is counted in vmcnt together with the volume stores, so each loop iteration would wait for the
 // previous iteration's stores to be acknowledged by memory.  As ds_read the gather only touches lgkmcnt
 // and the stores stay in flight.
 typedef const __attribute__((address_space(3))) float *LdsSrc;
 typedef const __attribute__((address_space(1))) float *GlobalSrc;
 typedef __attribute__((address_space(1))) float *GlobalOut;  // the output volume
+typedef __attribute__((address_space(1))) int *GlobalPix;    // the diagnostic pixel map
 
+// A staged rectangle in LDS (TSDF_FILL 0): addressed like the crop in global memory (row * stride + column,
+// coordinates relative to the rectangle), only in LDS.
+struct LdsRect {
+  LdsSrc p;
+};
+
+// Depth of pixel (ex, row): pre/tsdf_numba.py:36-39.  `ent` is the row's pool entry (LDS) or its
+// rectangle-relative index (global); inb = the pixel exists in the source.  The load is always in bounds.
+__device__ __forceinline__ float gather_px(const LdsSrc pool, const VoxK &, int ex, int, unsigned ent, bool &inb) {
+  const int rel = ex - (int)((ent >> 9) & 511u);
+  inb = (unsigned)rel < (ent & 511u);
+  const int idx = inb ? (int)((ent >> 18) << 2) + rel : 0;
+  return pool[idx];
+}
+__device__ __forceinline__ float gather_px(const GlobalSrc src, const VoxK &k, int ex, int ry, unsigned, bool &inb) {
+  inb = (ex | ry) >= 0;
+  int idx = __mul24(ry, k.stride) + ex + k.base;
+  idx = inb ? idx : k.base;
+  return src[idx];
+}
+__device__ __forceinline__ float gather_px(const LdsRect src, const VoxK &k, int ex, int ry, unsigned, bool &inb) {
+  inb = (ex | ry) >= 0;
+  int idx = __mul24(ry, k.stride) + ex + k.base;
+  idx = inb ? idx : k.base;
+  return src.p[idx];
+}
+
+// Per-voxel value, pre/tsdf_numba.py:36-68, for the 4 voxels of one lane.  Coordinates are pre-scaled
+// by it = 1/trunc_dis:  tx = v_x*it - (pix_x-cx)*(pd*kq),  ty likewise,  tz = v_z*it + pd*it (w_z = -pd).
+//   ex[j], ry[j], ent[j]  relative pixel of voxel j (ex -1: rejected) and its row's entry
+//   vxs[j], vys, vzs[j]   pre-scaled voxel centre;   negthr[j] = f32_round_up(-v_z)
+// Returns the mask of voxels that passed :36 and :40 (bit j).
 template <class SrcP>
-__device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry)[4], const double (&vxs)[4],
-                                              const double vys, const double (&vzs)[4],
-                                              const float (&negthr)[4], const VoxK &k,
-                                              const SrcP src, f4 &o0, f4 &o1, f4 &o2) {
+__device__ __forceinline__ unsigned voxel_values4(const int (&ex)[4], const int (&ry)[4], const unsigned (&ent)[4],
+                                                  const double (&vxs)[4], const double vys, const double (&vzs)[4],
+                                                  const float (&negthr)[4], const VoxK &k,
+                                                  const SrcP src, f4 &o0, f4 &o1, f4 &o2) {
   float pd[4];
   bool inb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    inb[j] = (ex[j] | ry[j]) >= 0;                                          // :36 (both in range)
-    int idx = __mul24(ry[j], k.stride) + ex[j] + k.base;
-    idx = inb[j] ? idx : k.base;
-    pd[j] = src[idx];                                                       // :38-39 (always in bounds)
-  }
+  for (int j = 0; j < 4; ++j) pd[j] = gather_px(src, k, ex[j], ry[j], ent[j], inb[j]);   // :36-39
   bool ok[4], neg[4];
   double pd64[4], tz[4];
   bool any_near = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    ok[j] = inb[j] & (__builtin_fabsf(pd[j]) >= k.eps);                     // :40
+    ok[j] = inb[j] & (__builtin_fabsf(pd[j]) >= k.eps);                     // :40 (NaN -> rejected)
     pd64[j] = (double)pd[j];
     tz[j] = __builtin_fma(pd64[j], k.it, vzs[j]);                           // :46,:49
     neg[j] = pd[j] < negthr[j];                                             // w_z > v_z  :65
@@ -590,6 +712,7 @@ __device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry
   }
   float *p0 = reinterpret_cast<float *>(&o0), *p1 = reinterpret_cast<float *>(&o1),
         *p2 = reinterpret_cast<float *>(&o2);
+  unsigned okm = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     // sign :65-68 and zero for rejected voxels :33-41 as bit masks
@@ -598,7 +721,9 @@ __device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry
     p0[j] = __uint_as_float((__float_as_uint(r0[j]) | sg) & keep);
     p1[j] = __uint_as_float((__float_as_uint(r1[j]) | sg) & keep);
     p2[j] = __uint_as_float((__float_as_uint(r2[j]) | sg) & keep);
+    okm |= (unsigned)ok[j] << j;
   }
+  return okm;
 }
 
 #ifndef TSDF_NT_STORE
@@ -608,8 +733,8 @@ __device__ __forceinline__ void voxel_values4(const int (&ex)[4], const int (&ry
 #define TSDF_TAIL_HELP 1
 #endif
 // One 16-byte store of the output volume.  It is written once and never re-read here, so it goes out
-// non-temporal: the depth rows this CU has just streamed stay in L2 / Infinity Cache for the staging
-// copy instead of being evicted by 393 KB of output per frame (measured: 180 -> 155 us per 1024 frames).
+// non-temporal and does not evict the depth rows other workgroups are streaming through L2 / Infinity
+// Cache (measured in round 1: 180 -> 155 us per 1024 frames).
 __device__ __forceinline__ void store_vol4(GlobalOut p, f4 v) {
 #if TSDF_NT_STORE
   __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f4 *)p);
@@ -618,14 +743,59 @@ __device__ __forceinline__ void store_vol4(GlobalOut p, f4 v) {
 #endif
 }
 
-// LDS-resident per-frame tables.  The pixel a voxel projects to factorises: pix_x depends on (x, z)
-// only and pix_y on (y, z) only, so for R <= kTabR both are tabulated once per frame (R*R entries
-// each, one pair per thread) instead of 3 float64 operations + a range test per voxel.
+// Diagnostic pixel map (tsdf_debug_pixmap_hip), one voxel: see include/tsdf.h.  `frame_dc/dr` shift the
+// tables' frame of reference back into the bounding box.
+struct PixMapK {
+  GlobalPix out;  // int32[R][R][R] of this frame, [z][y][x]; null: no map
+  int bw, dc, dr;
+};
+__device__ __forceinline__ int pixmap_value(const PixMapK &pm, int ex, int ry, bool row_in_bbox, bool ok) {
+  if (ex < 0 || !row_in_bbox) return -1;                      // :36-37
+  const int idx = (ry + pm.dr) * pm.bw + ex + pm.dc;          // :38
+  return ok ? idx : -2 - idx;                                 // :40-41
+}
+
+// LDS-resident per-frame tables, one set per group.  The pixel a voxel projects to factorises: pix_x
+// depends on (x, z) only and pix_y on (y, z) only, so for R <= kTabR both are tabulated once per frame
+// (R*R entries each, one pair per thread) instead of 3 float64 operations + a range test per voxel.
+//   pxtab[.]  relative pix_x, or -1
+//   pytab[.]  LDS gather: the pool entry of row pix_y (0: outside the bounding box)
+//             global gather: relative pix_y, or -1
+//   pyrow[.]  LDS gather: relative pix_y (0 when outside)              (uint8; rows < kMaxRows)
 struct ZEntry {
   double q;      // -F / v_z                     :30
   double vzs;    // v_z / trunc_dis
   float negthr;  // f32_round_up(-v_z)
   float pad;
+};
+
+typedef __attribute__((address_space(3))) const ZEntry *LdsZ;
+typedef __attribute__((address_space(3))) const int *LdsCI;
+typedef __attribute__((address_space(3))) const unsigned *LdsCU;
+typedef __attribute__((address_space(3))) const unsigned char *LdsCU8;
+typedef __attribute__((address_space(3))) const double *LdsCD;
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const i4v *LdsI4;
+typedef __attribute__((address_space(3))) const u4v *LdsU4;
+
+__device__ __forceinline__ ZEntry load_z(LdsZ p) {
+  ZEntry z;
+  z.q = p->q;
+  z.vzs = p->vzs;
+  z.negthr = p->negthr;
+  z.pad = 0.f;
+  return z;
+}
+
+struct Tabs {
+  LdsZ ztab;
+  LdsCI pxtab;
+  LdsCU pytab;
+  LdsCU8 pyrow;
+  LdsCU rowtab;
+  LdsCD atab;
 };
 
 // table index of (fast, slow) coordinates: the 4 entries a lane needs are contiguous
@@ -634,13 +804,28 @@ __device__ __forceinline__ int tab_index(int x_or_y, int z, int R) {
   return LAYOUT == 0 ? z * R + x_or_y : x_or_y * R + z;
 }
 
-template <int LAYOUT, int T, class SrcP>
-__device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R,
-                                       const ZEntry *ztab, const int *pxtab, const int *pytab,
-                                       const bool use_tab, const SrcP src,
-                                       const GlobalOut out, const int tid) {
-  // tid in [0, T): T = kGW when the group works alone, 2*kGW when the CU's other group helps (its
-  // threads come in as kGW + gtid)
+template <class SrcP>
+struct IsLds {
+  static constexpr bool value = std::is_same<SrcP, LdsSrc>::value;
+};
+
+// row entry for an on-the-fly projected row (no tables): LDS gather looks the row table up
+template <class SrcP>
+__device__ __forceinline__ unsigned row_entry(const Tabs &tb, int ry) {
+  if constexpr (IsLds<SrcP>::value) {
+    return ry >= 0 ? tb.rowtab[ry] : 0u;
+  } else {
+    return (unsigned)ry;
+  }
+}
+
+// The voxel pass over slow-axis slices [sb, se).  T threads take part (tid in [0, T)): T = kGW when a group
+// works alone, 2*kGW when the CU's other group helps (its threads come in as kGW + gtid), kWG in the split
+// kernel.
+template <int LAYOUT, int T, bool DBG, class SrcP>
+__device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R, const Tabs &tb,
+                                       const bool use_tab, const SrcP src, const GlobalOut out, const int tid,
+                                       const int sb, const int se, const PixMapK &pm) {
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1];
   const int R4 = R / 4;
@@ -673,126 +858,95 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
         vx[j] = ox + (double)(f4i + j) * vl;                                // :26
         vxs[j] = vx[j] * vk.it;
       }
-      for (int z = s0; z < R; z += sstep) {
-        const ZEntry ze = ztab[z];
+      for (int z = sb + s0; z < se; z += sstep) {
+        const ZEntry ze = load_z(tb.ztab + z);
         int ex[4], ry[4];
+        unsigned ent[4];
         if (use_tab) {
-          const int4 e = *reinterpret_cast<const int4 *>(pxtab + z * R + f4i);
+          const i4v e = *(LdsI4)(tb.pxtab + z * R + f4i);
           ex[0] = e.x; ex[1] = e.y; ex[2] = e.z; ex[3] = e.w;
-          ry[0] = pytab[z * R + y];
+          ent[0] = tb.pytab[z * R + y];
+          ry[0] = IsLds<SrcP>::value ? (int)tb.pyrow[z * R + y] : (int)ent[0];
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) ex[j] = project_rel(vx[j], ze.q, cam.cx, vk.px0, vk.dx);  // :31
           ry[0] = project_rel(-vy, ze.q, cam.cy, vk.py0, vk.dy);                                 // :32
+          ent[0] = row_entry<SrcP>(tb, ry[0]);
         }
         ry[1] = ry[2] = ry[3] = ry[0];
+        ent[1] = ent[2] = ent[3] = ent[0];
         const double vzs[4] = {ze.vzs, ze.vzs, ze.vzs, ze.vzs};
         const float negthr[4] = {ze.negthr, ze.negthr, ze.negthr, ze.negthr};
         f4 o0, o1, o2;
-        voxel_values4(ex, ry, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
+        const unsigned okm = voxel_values4(ex, ry, ent, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
         const int64_t e = ((int64_t)z * R + y) * R + f4i;                   // o[c][z][y][x] :70-72
         store_vol4(out + e, o0);
         store_vol4(out + R3 + e, o1);
         store_vol4(out + 2 * R3 + e, o2);
+        if constexpr (DBG) {
+          const bool rin = IsLds<SrcP>::value ? ent[0] != 0u : ry[0] >= 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pm.out[e + j] = pixmap_value(pm, ex[j], ry[0], rin, (okm >> j) & 1u);
+        }
       }
     } else {
       // lanes run along z: q, v_z and pix_y fixed per lane, loop over x
       double q[4], vzs[4];
       float negthr[4];
       int ry[4];
+      unsigned ent[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const ZEntry ze = ztab[f4i + j];
+        const ZEntry ze = load_z(tb.ztab + f4i + j);
         q[j] = ze.q;
         vzs[j] = ze.vzs;
         negthr[j] = ze.negthr;
       }
       if (use_tab) {
-        const int4 e = *reinterpret_cast<const int4 *>(pytab + y * R + f4i);
-        ry[0] = e.x; ry[1] = e.y; ry[2] = e.z; ry[3] = e.w;
+        const u4v e = *(LdsU4)(tb.pytab + y * R + f4i);
+        ent[0] = e.x; ent[1] = e.y; ent[2] = e.z; ent[3] = e.w;
+        if constexpr (IsLds<SrcP>::value) {
+          const unsigned rr = *(LdsCU)(tb.pyrow + y * R + f4i);
+          ry[0] = rr & 255u; ry[1] = (rr >> 8) & 255u; ry[2] = (rr >> 16) & 255u; ry[3] = rr >> 24;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ry[j] = (int)ent[j];
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ry[j] = project_rel(-vy, q[j], cam.cy, vk.py0, vk.dy);
+        for (int j = 0; j < 4; ++j) {
+          ry[j] = project_rel(-vy, q[j], cam.cy, vk.py0, vk.dy);
+          ent[j] = row_entry<SrcP>(tb, ry[j]);
+        }
       }
-      for (int x = s0; x < R; x += sstep) {
+      for (int x = sb + s0; x < se; x += sstep) {
         const double vx = ox + (double)x * vl;
         const double vx1 = vx * vk.it;
         const double vxs[4] = {vx1, vx1, vx1, vx1};
         int ex[4];
         if (use_tab) {
-          const int4 e = *reinterpret_cast<const int4 *>(pxtab + x * R + f4i);
+          const i4v e = *(LdsI4)(tb.pxtab + x * R + f4i);
           ex[0] = e.x; ex[1] = e.y; ex[2] = e.z; ex[3] = e.w;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) ex[j] = project_rel(vx, q[j], cam.cx, vk.px0, vk.dx);
         }
         f4 o0, o1, o2;
-        voxel_values4(ex, ry, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
+        const unsigned okm = voxel_values4(ex, ry, ent, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
         const int64_t e = ((int64_t)x * R + y) * R + f4i;                   // o[c][x][y][z] tsdf_for.py:118-120
         store_vol4(out + e, o0);
         store_vol4(out + R3 + e, o1);
         store_vol4(out + 2 * R3 + e, o2);
+        if constexpr (DBG) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool rin = IsLds<SrcP>::value ? ent[j] != 0u : ry[j] >= 0;
+            pm.out[((int64_t)(f4i + j) * R + y) * R + x] = pixmap_value(pm, ex[j], ry[j], rin, (okm >> j) & 1u);
+          }
+        }
       }
     }
   }
-}
-
-// ---- synchronisation inside one half-workgroup (group) -------------------------------------------
-// s_barrier spans all 16 waves, so the 8 waves of a group meet on an LDS counter instead: monotonic
-// count, lane 0 of each wave adds 1 and polls until the group's epoch target is reached.  LDS
-// operations of a wave execute in order, so everything a wave wrote to LDS before its arrival is
-// visible to whoever sees the count.  Only LDS is ordered here (no vmcnt wait: output stores stay
-// in flight across these barriers).
-struct FrameHdr {
-  int frame;  // -1: no more work
-  int l, t, r, b;
-  int pad;
-  int64_t off0, off1;
-};
-
-// Tail help: a group that finds the queue empty does not leave at once.  It raises idle[] and waits; the
-// CU's other group, on reaching phase 2 of what is then necessarily its last frame, sees the flag, posts
-// the frame's voxel parameters here and both groups split the slow axis of the volume (the stage and the
-// tables are in LDS, which the two share).  Nothing has to be handed back: the helper leaves when done.
-struct HelpReq {
-  Grid g;
-  VoxK vk;
-  const float *src;  // the frame in global memory (gather source when the rectangle is not staged)
-  float *out;
-  int frame, use_tab, staged, pad;
-};
-
-struct GroupCtl {
-  int bar[kGroups];
-  int lock;  // 0 free, 1 held: the LDS stage + tables are one resource the two groups take turns on
-  int help_for;  // 0: none; g+1: group g is asked to help with the frame in `help`
-  int idle[kGroups];
-  FrameHdr hdr[kGroups];  // mailbox: the group's first wave fetches the next frame for the others
-  HelpReq help;
-};
-
-__device__ __forceinline__ int lds_load(const int *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store(int *p, int v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// Work queue: frames beyond the first one per group are handed out dynamically (frame cost varies
-// ~3x with the hand's size; a static 4-frames-per-CU split left a 25 % tail).  One slot per launch in
-// flight; `next` and `done` return to 0 when the launch's last group leaves, so a slot needs no reset.
-constexpr int kQueueSlots = 1024;  // launches that may be in flight at once (8 KiB of device memory)
-__device__ unsigned int g_queue[kQueueSlots][2];
-
-__device__ __forceinline__ void group_barrier(int *cnt, int &target) {
-  target += kGWaves;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) {
-    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-      __builtin_amdgcn_s_sleep(1);
-  }
-  asm volatile("" ::: "memory");
 }
 
 // Phase 2 of the augmented form (oracle/tsdf_oracle.c::tsdf_oracle_voxels_aug): the voxel centre v'
@@ -804,13 +958,13 @@ __device__ __forceinline__ void group_barrier(int *cnt, int &target) {
 // atab layout: [axis][index][row] = fl(inv[4*row + axis] * (ori_axis + index*voxel_len)).
 template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
-                                           const double *xf, const double *atab, const SrcP src,
-                                           const GlobalOut out, const int tid) {
+                                           const double *xf, const Tabs &tb, const SrcP src,
+                                           const GlobalOut out, const int tid, const int sb, const int se) {
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
   const double *fwd = xf, *inv = xf + 12;
   const double bi0 = inv[3], bi1 = inv[7], bi2 = inv[11];
-  const double *tabx = atab, *taby = atab + 3 * R, *tabz = atab + 6 * R;
+  const LdsCD tabx = tb.atab, taby = tb.atab + 3 * R, tabz = tb.atab + 6 * R;
   const int R4 = R / 4;
   const int G = R * R4;
   const int64_t R3 = (int64_t)R * R * R;
@@ -831,7 +985,7 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     const int y = gi / R4;
     const double vpy = oy + (double)y * vl;
     const double ty0 = taby[3 * y], ty1 = taby[3 * y + 1], ty2 = taby[3 * y + 2];
-    for (int sl = s0; sl < R; sl += sstep) {
+    for (int sl = sb + s0; sl < se; sl += sstep) {
       // ---- project the 4 voxels and gather their depths ----
       int ex[4], ry[4];
       float pd[4];
@@ -843,17 +997,15 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         const int x = LAYOUT == 0 ? f4i + j : sl, z = LAYOUT == 0 ? sl : f4i + j;
         vpx[j] = ox + (double)x * vl;
         vpz[j] = oz + (double)z * vl;
-        const double *tx = tabx + 3 * x, *tzp = tabz + 3 * z;
+        const LdsCD tx = tabx + 3 * x, tzp = tabz + 3 * z;
         const double vx = ((tx[0] + ty0) + tzp[0]) + bi0;                        // v = T^-1(v')
         const double vy = ((tx[1] + ty1) + tzp[1]) + bi1;
         const double vz = ((tx[2] + ty2) + tzp[2]) + bi2;
         const double q = -cam.focal / vz;                                        // :30
         ex[j] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                       // :31
         ry[j] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);                      // :32
-        const bool inb = (ex[j] | ry[j]) >= 0;                                   // :36
-        int idx = __mul24(ry[j], vk.stride) + ex[j] + vk.base;
-        idx = inb ? idx : vk.base;
-        pd[j] = src[idx];                                                        // :38-39
+        bool inb;
+        pd[j] = gather_px(src, vk, ex[j], ry[j], row_entry<SrcP>(tb, ry[j]), inb);  // :36-39
         ok[j] = inb & (__builtin_fabsf(pd[j]) >= vk.eps);                        // :40
       }
       // ---- z component first: a wave whose voxels are all beyond the truncation distance along z' alone
@@ -909,44 +1061,364 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
   }
 }
 
-// Persistent kernel, one 1024-thread workgroup per CU.  Its two 512-thread groups each walk their
-// own frames  (frame = blockIdx.x + gridDim.x * (group + 2*i))  through
-//     stream rows -> extents -> glue        (no shared resource; the memory-bound part)
-//     [ tables -> stage -> phase 2 ]        (holds the LDS stage; the VALU/store-bound part)
-// and take turns on the single 128 KiB LDS stage, so one group's row streaming overlaps the other
-// group's voxel arithmetic and stores on the same CU.
-template <int RT, int LAYOUT, bool AUG>
-__global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
-    const float *__restrict__ depth, const int64_t *__restrict__ offsets,
-    const int32_t *__restrict__ headers, int n, int Rrt, CamK cam, float *__restrict__ out_tsdf,
-    float *__restrict__ out_max_l, float *__restrict__ out_mid_p, int32_t *__restrict__ out_status,
-    float *__restrict__ out_aabb, float *__restrict__ out_grid, float *__restrict__ out_ori,
-    int aabb_only, const float *__restrict__ grid_in, int qslot, const double *__restrict__ xforms,
-    int64_t depth_len) {
-  __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
-  __shared__ __attribute__((aligned(16))) int pxtab[kTabR * kTabR];
-  __shared__ __attribute__((aligned(16))) int pytab[kTabR * kTabR];
-  __shared__ __attribute__((aligned(16))) ZEntry ztab[kMaxR];
-  __shared__ __attribute__((aligned(16))) double atab[AUG ? 9 * kMaxR : 1];  // inverse-map products (AUG)
-  __shared__ float red_all[kGroups][kGWaves * kRedStride];
-  __shared__ GroupCtl ctl;
 
-  const int R = RT ? RT : Rrt;
+// ---- kernel arguments ---------------------------------------------------------------------------
+struct KArgs {
+  const float *depth;
+  const int64_t *offsets;
+  const int32_t *headers;
+  int n, R;
+  CamK cam;
+  float *tsdf, *max_l, *mid_p;
+  int32_t *status;
+  float *aabb, *grid, *ori;
+  int aabb_only;
+  const float *grid_in;
+  unsigned int *queue;    // this launch's work-queue word, or null: CU-local queues (see the kernel)
+  const double *xforms;
+  int64_t depth_len;
+  const float *gt;        // labels (optional)
+  float *gt_nor, *gt_aug;
+  int n_joints, clamp;
+  int32_t *pixmap;        // diagnostic pixel map (DBG instantiations only)
+  int split, per;         // split kernel: workgroups per frame, slow-axis slices per workgroup
+};
+
+// ---- synchronisation inside one half-workgroup (group) -------------------------------------------
+// s_barrier spans all 16 waves, so the 8 waves of a group meet on an LDS counter instead: monotonic
+// count, lane 0 of each wave adds 1 and polls until the group's epoch target is reached.  LDS
+// operations of a wave execute in order, so everything a wave wrote to LDS before its arrival is
+// visible to whoever sees the count.  Only LDS is ordered here (no vmcnt wait: output stores stay
+// in flight across these barriers).
+struct FrameHdr {
+  int frame;  // -1: no more work
+  int l, t, r, b;
+  int pad;
+  int64_t off0, off1;
+};
+
+// Tail help: a group that finds the queue empty does not leave at once.  It raises idle[] and waits; the
+// CU's other group, on reaching phase 2 of what is then necessarily its last frame, sees the flag, posts
+// the frame's voxel parameters here and both groups split the slow axis of the volume (the pool and the
+// tables are in LDS, which the two share).  Nothing has to be handed back: the helper leaves when done.
+struct HelpReq {
+  Grid g;
+  VoxK vk;
+  const float *src;  // the frame in global memory (gather source when the frame was not captured)
+  float *out;
+  int frame, use_tab, mode, owner;  // mode: FillMode
+  int pm_bw, pm_dc, pm_dr, pad;     // diagnostic map: see PixMapK
+};
+
+struct GroupCtl {
+  int bar[kGroups];
+  int local_next;         // CU-local work queue (launches without a global queue word)
+  int lock;               // TSDF_P2_LOCK builds: one group at a time between the extents barrier and the end of phase 2
+  int help_for;           // 0: none; g+1: group g is asked to help with the frame in `help`
+  int idle[kGroups];
+  int cap_fail[kGroups];  // a row of the group's current frame did not fit the pool
+  FrameHdr hdr[kGroups];  // mailbox: the group's first wave fetches the next frame for the others
+  HelpReq help;
+};
+
+// How the fused kernel gets a frame's pixels into LDS for the voxel pass:
+//   TSDF_FILL 0  after phase 1, the rectangle holding every valid pixel is copied into the pool by LDS-DMA
+//                (global_load_lds_dwordx4: no VGPR staging, all of a wave's 1 KiB pieces in flight at once); the
+//                pool is ONE resource the two groups take turns on through a lock taken on the way into the
+//                extents barrier.  The rows come from L2 / Infinity Cache a second time (+10 % fabric traffic).
+//   TSDF_FILL 1  row-span capture during phase 1 (see Capture): depth is read exactly once and there is no lock,
+//                but the capture's LDS stores sit on the row stream's critical path and a frame whose spans do
+//                not fit takes the much slower global gather.  Measured slower on every workload.
+// The split kernel always captures (one frame per workgroup: everything fits, nothing to take turns on).
+#ifndef TSDF_FILL
+#define TSDF_FILL 0
+#endif
+#ifndef TSDF_P2_LOCK
+#define TSDF_P2_LOCK (TSDF_FILL == 0)
+#endif
+constexpr bool kCaptureFill = TSDF_FILL == 1;
+
+__device__ __forceinline__ int lds_load(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(int *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void group_barrier(int *cnt, int &target) {
+  target += kGWaves;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
+// ---- the workgroup's LDS: everything the CU has --------------------------------------------------
+// Per group: projection tables, z table, (AUG) inverse-map products, row table, reduction scratch.
+// Shared: control block and the row-span pool, which gets all the rest.
+template <int RT, bool AUG>
+struct Lds {
+  static constexpr int kZ = RT ? RT : kMaxR;
+  static constexpr bool kHasTab = !AUG && (RT == 0 || RT <= kTabR);
+  static constexpr int kTabN = kHasTab ? kTabR * kTabR : 16;
+  struct PerGroup {
+    alignas(16) unsigned pytab[kTabN];
+    alignas(16) int pxtab[kTabN];
+    alignas(16) unsigned char pyrow[kTabN];
+    alignas(16) ZEntry ztab[kZ];
+    alignas(16) double atab[AUG ? 9 * kZ : 2];
+    alignas(16) unsigned rowtab[kMaxRows];
+    alignas(16) float red[16 * kRedStride];  // 16 waves in the split kernel
+  };
+  static constexpr int kFixed = kGroups * (int)sizeof(PerGroup) + (int)sizeof(GroupCtl) + 64;
+  static constexpr int kPoolFloats = ((kLdsBytes - kFixed) / 16) * 4;
+  static constexpr int kPoolUnits = kPoolFloats / 4;
+  static_assert(kPoolUnits < 16384, "pool offsets are 14 bits of 4-float units");
+  struct Block {
+    alignas(16) float pool[kPoolFloats];
+    PerGroup pg[kGroups];
+    alignas(16) GroupCtl ctl;
+  };
+  static_assert(sizeof(Block) <= kLdsBytes, "LDS layout exceeds the CU");
+};
+
+template <class PG>
+__device__ __forceinline__ Tabs make_tabs(PG &pg) {
+  Tabs t;
+  t.ztab = (LdsZ)pg.ztab;
+  t.pxtab = (LdsCI)pg.pxtab;
+  t.pytab = (LdsCU)pg.pytab;
+  t.pyrow = (LdsCU8)pg.pyrow;
+  t.rowtab = (LdsCU)pg.rowtab;
+  t.atab = (LdsCD)pg.atab;
+  return t;
+}
+
+// ---- per-frame pieces shared by the fused and the split kernel ------------------------------------
+// A header that contradicts its payload, or a payload outside the depth buffer, is never read.
+__device__ __forceinline__ bool frame_from_header(const FrameHdr &fh, const float *depth, int64_t depth_len, Frame &f) {
+  f.l = __builtin_amdgcn_readfirstlane(fh.l);
+  f.t = __builtin_amdgcn_readfirstlane(fh.t);
+  f.r = __builtin_amdgcn_readfirstlane(fh.r);
+  f.b = __builtin_amdgcn_readfirstlane(fh.b);
+  const int64_t bw = (int64_t)f.r - f.l, bh = (int64_t)f.b - f.t;  // cannot overflow in 64 bits
+  f.bw = (int)bw;
+  f.bh = (int)bh;
+  f.depth = depth + fh.off0;
+  return bw > 0 && bh > 0 && bw <= 0x7fffffff && bh <= 0x7fffffff && bw * bh == fh.off1 - fh.off0 && fh.off0 >= 0 &&
+         fh.off1 <= depth_len;
+}
+
+__device__ __forceinline__ bool finite32(float v) { return __builtin_fabsf(v) < TSDF_INF; }
+
+// AABB -> grid placement and frame status (degenerate-frame rule of include/tsdf.h).
+__device__ __forceinline__ void place_grid(Aabb &ab, int R, const CamK &cam, const float *grid_in, int frame,
+                                           Grid &g, int &status) {
+  if (!ab.any) {
+    status = TSDF_FRAME_DEGENERATE;
+    ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+    return;
+  }
+  g = glue(ab.mn, ab.mx, R, cam);
+  if (grid_in) {
+    // caller-supplied placement (tsdf_cal's vox_ori, voxel_len, truncation arguments)
+    const float *gi = grid_in + 8 * (int64_t)frame;
+    g.ori[0] = gi[0];
+    g.ori[1] = gi[1];
+    g.ori[2] = gi[2];
+    g.voxel_len = gi[3];
+    g.trunc = gi[4];
+    if (!(g.trunc > 0.f) || !(g.trunc < TSDF_INF)) status = TSDF_FRAME_DEGENERATE;
+    return;
+  }
+  const bool mid_ok = finite32(g.mid[0]) && finite32(g.mid[1]) && finite32(g.mid[2]);
+  if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF) || !mid_ok) {
+    status = TSDF_FRAME_DEGENERATE;
+    g.max_l = g.voxel_len = g.trunc = 0.f;
+    if (!mid_ok) g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
+  }
+}
+
+// one thread per frame writes the scalars
+__device__ __forceinline__ void write_frame_outputs(const KArgs &a, int frame, const Grid &g, const Aabb &ab, int status) {
+  if (a.max_l) a.max_l[frame] = g.max_l;
+  if (a.mid_p) {
+    a.mid_p[3 * (int64_t)frame + 0] = g.mid[0];
+    a.mid_p[3 * (int64_t)frame + 1] = g.mid[1];
+    a.mid_p[3 * (int64_t)frame + 2] = g.mid[2];
+  }
+  if (a.status) a.status[frame] = status;
+  if (a.aabb) {
+    float *o = a.aabb + 6 * (int64_t)frame;
+    o[0] = ab.mn[0]; o[1] = ab.mn[1]; o[2] = ab.mn[2];
+    o[3] = ab.mx[0]; o[4] = ab.mx[1]; o[5] = ab.mx[2];
+  }
+  if (a.grid) {
+    float *q = a.grid + 8 * (int64_t)frame;
+    q[0] = g.mid[0]; q[1] = g.mid[1]; q[2] = g.mid[2];
+    q[3] = g.max_l; q[4] = g.voxel_len; q[5] = g.trunc; q[6] = 0.f; q[7] = 0.f;
+  }
+  if (a.ori) {
+    float *q = a.ori + 3 * (int64_t)frame;
+    q[0] = g.ori[0]; q[1] = g.ori[1]; q[2] = g.ori[2];
+  }
+}
+
+// Labels: pre/joint_nor.py:8-18 + the clamp of 3D_CNN/train.py:241-242, float32, three separately rounded
+// operations; AUG maps the joints with the frame's forward map first (pre/process.py:232-249 does it with the
+// cloud's S and R).  Frames that are not OK get 0.5 (see include/tsdf.h).
+__device__ __forceinline__ void write_labels(const KArgs &a, int frame, const Grid &g, int status, const double *xf,
+                                             int tid, int T) {
+  if (!a.gt) return;
+  const int nc = 3 * a.n_joints;
+  for (int e = tid; e < nc; e += T) {
+    const int c = e % 3;
+    const float *gj = a.gt + (int64_t)frame * nc + (e - c);
+    float v = gj[c];
+    if (xf) {
+      v = (float)affine_row(xf + 4 * c, (double)gj[0], (double)gj[1], (double)gj[2]);
+      if (a.gt_aug) a.gt_aug[(int64_t)frame * nc + e] = v;
+    }
+    float o = 0.5f;
+    if (status == TSDF_FRAME_OK) {
+      const float m = c == 0 ? g.mid[0] : (c == 1 ? g.mid[1] : g.mid[2]);
+      o = __fadd_rn(__fdiv_rn(__fsub_rn(v, m), g.max_l), 0.5f);
+      if (a.clamp) {
+        o = o < 0.f ? 0.f : o;
+        o = o > 1.f ? 1.f : o;
+      }
+    }
+    a.gt_nor[(int64_t)frame * nc + e] = o;
+  }
+}
+
+// How a frame's pixels reach the voxel pass.
+enum FillMode {
+  kFillGlobal = 0,  // gather from the crop in global memory (L2)
+  kFillSpans = 1,   // row spans captured into the pool during phase 1; per-row entries
+  kFillRect = 2     // rectangle of valid pixels staged into the pool by LDS-DMA after phase 1
+};
+
+// Voxel-pass constants.  Pixel coordinates are relative to a frame of reference: the bounding box for span
+// entries, the rectangle holding every valid pixel otherwise (whole_bbox: the bounding box there too — the
+// diagnostic map has to tell "outside the bounding box" from "invalid pixel").
+__device__ __forceinline__ VoxK make_voxk(const CamK &cam, const Grid &g, const Frame &f, const Aabb &ab,
+                                          int mode, bool whole_bbox, int rect_stride) {
+  VoxK vk;
+  vk.cx = cam.cx;
+  vk.cy = cam.cy;
+  vk.it = 1.0 / (double)g.trunc;
+  vk.kq = cam.inv_focal * vk.it;
+  vk.ncx = -cam.cx;
+  vk.eps = cam.eps;
+  int c0 = ab.c0, r0 = ab.r0, w = ab.c1 - ab.c0 + 1, h = ab.r1 - ab.r0 + 1;
+  if (mode == kFillSpans || whole_bbox) {
+    c0 = r0 = 0;
+    w = f.bw;
+    h = f.bh;
+  }
+  vk.px0 = f.l + c0;
+  vk.py0 = f.t + r0;
+  vk.dx = w - 1;
+  vk.dy = h - 1;
+  vk.stride = mode == kFillRect ? rect_stride : f.bw;
+  vk.base = mode == kFillGlobal ? r0 * f.bw + c0 : 0;
+  return vk;
+}
+
+// Per-frame tables (true divisions; (x,z)/(y,z) pairs spread over the T participating threads).
+template <int LAYOUT, bool AUG, class PG>
+__device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &cam, const VoxK &vk, int R,
+                                            bool use_tab, bool spans, const double *xf, int vt, int T) {
+  const double vl = (double)g.voxel_len;
+  const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
+  if (vt < R) {
+    const double v_z = oz + (double)vt * vl;  // :28
+    ZEntry ze;
+    ze.q = -cam.focal / v_z;                    // :30
+    ze.vzs = v_z * vk.it;
+    ze.negthr = f32_round_up(-v_z);             // pd < -v_z  <=>  w_z > v_z  (:65)
+    ze.pad = 0.f;
+    pg.ztab[vt] = ze;
+  }
+  if constexpr (AUG) {
+    // products of the inverse map, one per (axis, index, row): see phase2_aug
+    const double *inv = xf + 12;
+    for (int e = vt; e < 9 * R; e += T) {
+      const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
+      const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
+      pg.atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
+    }
+  }
+  if (use_tab) {
+    for (int e = vt; e < R * R; e += T) {
+      const int z = e / R, i = e - z * R;
+      const double q = -cam.focal / (oz + (double)z * vl);                              // :30
+      const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
+      const int ti = tab_index<LAYOUT>(i, z, R);
+      pg.pxtab[ti] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                         // :31
+      const int ry = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);                        // :32
+      if (spans) {
+        pg.pytab[ti] = ry >= 0 ? pg.rowtab[ry] : 0u;
+        pg.pyrow[ti] = (unsigned char)(ry >= 0 ? ry : 0);
+      } else {
+        pg.pytab[ti] = (unsigned)ry;
+      }
+    }
+  }
+}
+
+// Work queue.  Frames beyond the first one per group are handed out dynamically (frame cost varies ~3x with
+// the hand's size; a static 4-frames-per-CU split left a 25 % tail).  An eager launch draws tickets from a
+// device-global word that belongs to its (device, stream) pair — launches of one stream run in order, so the
+// word is never shared (host side: queue_word()).  Exactly n tickets are drawn per launch (every group that
+// got a positional frame draws until it fails once), so whoever draws ticket n-1 knows it is the last and
+// puts the word back to 0: nothing to reset between launches.  A launch without such a word (captured into
+// a graph, or more streams than words) shares frames inside each CU only, through a counter in LDS.
+constexpr int kQueueSlots = 1024;
+__device__ unsigned int g_queue[kQueueSlots];
+
+// Persistent kernel, one 1024-thread workgroup per CU.  Its two 512-thread groups each walk their own
+// frames through
+//     stream rows (+ capture the valid spans into the LDS pool) -> extents -> glue    memory-bound
+//     tables -> voxel pass from the pool                                               VALU/store-bound
+// independently of each other, so one group's row streaming overlaps the other group's voxel arithmetic
+// and stores on the same CU.
+template <int RT, int LAYOUT, bool AUG, bool DBG>
+__global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
+  using L = Lds<RT, AUG>;
+  __shared__ typename L::Block lds;
+
+  const int R = RT ? RT : a.R;
+  const CamK &cam = a.cam;
+  const int n = a.n;
   const int tid = threadIdx.x, lane = tid & 63, gtid = tid & (kGW - 1);
   const int group = __builtin_amdgcn_readfirstlane(tid / kGW);
   const int gwave = __builtin_amdgcn_readfirstlane((tid >> 6) & (kGWaves - 1));
-  float *red = red_all[group];
+  auto &pg = lds.pg[group];
+  GroupCtl &ctl = lds.ctl;
 
   if (tid == 0) {
-    for (int i = 0; i < kGroups; ++i) ctl.bar[i] = ctl.idle[i] = 0;
+    for (int i = 0; i < kGroups; ++i) ctl.bar[i] = ctl.idle[i] = ctl.cap_fail[i] = 0;
     ctl.lock = 0;
     ctl.help_for = 0;
+    ctl.local_next = kGroups;
   }
   __syncthreads();  // the only workgroup-wide barrier
   int bar_target = 0;
   auto gsync = [&]() { group_barrier(&ctl.bar[group], bar_target); };
 
-  unsigned int *q_next = &g_queue[qslot][0], *q_done = &g_queue[qslot][1];
+  Capture cap;
+  cap.pool = (LdsF)lds.pool;
+  cap.rowtab = (LdsU)pg.rowtab;
+  cap.fail = (LdsI)&ctl.cap_fail[group];
+  cap.cap4 = L::kPoolUnits / (kWG / 64);
+  cap.base4 = __builtin_amdgcn_readfirstlane(tid >> 6) * cap.cap4;
+  cap.on = false;
+
   const int n_static = gridDim.x * kGroups;  // frames handed out by position (the first one per group)
 
   int iter = 0;
@@ -957,25 +1429,36 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
       int fr;
       if (iter == 0) {
         fr = blockIdx.x + gridDim.x * group;
-      } else {
+      } else if (a.queue) {
         unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(q_next, 1u);
+        if (lane == 0) {
+          t = atomicAdd(a.queue, 1u);
+          if (t == (unsigned int)(n - 1)) __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         fr = n_static + (int)__builtin_amdgcn_readfirstlane(t);
+      } else {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&ctl.local_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int64_t f64i = (int64_t)blockIdx.x + (int64_t)gridDim.x * __builtin_amdgcn_readfirstlane(t);
+        fr = f64i < n ? (int)f64i : n;
       }
       FrameHdr m;
       m.frame = fr < n ? fr : -1;
       m.l = m.t = m.r = m.b = m.pad = 0;
       m.off0 = m.off1 = 0;
       if (fr < n) {
-        const int32_t *h = headers + 6 * (int64_t)fr;
+        const int32_t *h = a.headers + 6 * (int64_t)fr;
         m.l = h[2];
         m.t = h[3];
         m.r = h[4];
         m.b = h[5];
-        m.off0 = offsets[fr];
-        m.off1 = offsets[fr + 1];
+        m.off0 = a.offsets[fr];
+        m.off1 = a.offsets[fr + 1];
       }
-      if (lane == 0) ctl.hdr[group] = m;
+      if (lane == 0) {
+        ctl.hdr[group] = m;
+        ctl.cap_fail[group] = 0;
+      }
     }
     gsync();
     const FrameHdr fh = ctl.hdr[group];
@@ -984,15 +1467,9 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     TSDF_STAMP(kGroups * iter + group, 0);
 
     Frame f;
-    f.l = __builtin_amdgcn_readfirstlane(fh.l);
-    f.t = __builtin_amdgcn_readfirstlane(fh.t);
-    f.r = __builtin_amdgcn_readfirstlane(fh.r);
-    f.b = __builtin_amdgcn_readfirstlane(fh.b);
-    f.bw = f.r - f.l;
-    f.bh = f.b - f.t;
-    f.depth = depth + fh.off0;
-    float *out = out_tsdf ? out_tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
-    const bool want_vol = !aabb_only && out;
+    const bool hdr_ok = frame_from_header(fh, a.depth, a.depth_len, f);
+    float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
+    const bool want_vol = !a.aabb_only && out;
 
     int status = TSDF_FRAME_OK;
     Aabb ab;
@@ -1004,108 +1481,73 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
     g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
     g.max_l = g.voxel_len = g.trunc = 0.f;
     g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
+    const double *xf = AUG ? a.xforms + 24 * (int64_t)frame : nullptr;
 
-    bool holds_stage = false;  // group-uniform
-    // a header that contradicts its payload, or a payload outside the depth buffer, is never read
-    if (f.bw <= 0 || f.bh <= 0 || (int64_t)f.bw * (int64_t)f.bh != fh.off1 - fh.off0 || fh.off0 < 0 ||
-        fh.off1 > depth_len) {
+    bool holds_lock = false;  // group-uniform
+    cap.on = false;
+    if (!hdr_ok) {
       status = TSDF_FRAME_BAD_HEADER;  // group-uniform
     } else {
       float fin[kExt];
-      // The group's first wave takes the stage lock on its way into the extents barrier, so the
-      // wait for the other group's phase 2 hides behind this group's own slowest wave.
-      auto sync_and_lock = [&]() {
+      cap.on = kCaptureFill && want_vol && f.bw <= kMaxCapW && f.bh <= kMaxRows;  // group-uniform
+      auto sync_ext = [&]() {
+#if TSDF_P2_LOCK
+        // The group's first wave takes the pool lock on its way into the extents barrier, so the wait for
+        // the other group's voxel pass hides behind this group's own slowest wave.
         if (want_vol && gwave == 0 && lane == 0) {
           while (atomicCAS(&ctl.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
         }
+#endif
         gsync();
       };
-      phase1_extents<kGWaves, AUG>(f, cam, 0, f.bh, red, fin, gwave, sync_and_lock, kGroups * iter + group,
-                                   AUG ? xforms + 24 * (int64_t)frame : nullptr);
-      holds_stage = want_vol;
+      phase1_extents<kGWaves, AUG, kCaptureFill>(f, cam, 0, f.bh, pg.red, fin, gwave, sync_ext, cap,
+                                                 kGroups * iter + group, xf);
+      holds_lock = TSDF_P2_LOCK && want_vol;
       ab = aabb_from_extents(fin);
       TSDF_STAMP(kGroups * iter + group, 4);
-      if (!ab.any) {
-        status = TSDF_FRAME_DEGENERATE;
-        ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
-      } else {
-        g = glue(ab.mn, ab.mx, R, cam);
-        if (grid_in) {
-          // caller-supplied placement (tsdf_cal's vox_ori, voxel_len, truncation arguments)
-          const float *gi = grid_in + 8 * (int64_t)frame;
-          g.ori[0] = gi[0];
-          g.ori[1] = gi[1];
-          g.ori[2] = gi[2];
-          g.voxel_len = gi[3];
-          g.trunc = gi[4];
-          if (!(g.trunc > 0.f) || !(g.trunc < TSDF_INF)) status = TSDF_FRAME_DEGENERATE;
-        } else if (!(g.max_l > 0.f) || !(g.max_l < TSDF_INF)) {
-          status = TSDF_FRAME_DEGENERATE;
-          g.max_l = g.voxel_len = g.trunc = 0.f;
-        }
-      }
+      place_grid(ab, R, cam, a.grid_in, frame, g, status);
     }
 
-    if (gtid == 0) {
-      if (out_max_l) out_max_l[frame] = g.max_l;
-      if (out_mid_p) {
-        out_mid_p[3 * (int64_t)frame + 0] = g.mid[0];
-        out_mid_p[3 * (int64_t)frame + 1] = g.mid[1];
-        out_mid_p[3 * (int64_t)frame + 2] = g.mid[2];
-      }
-      if (out_status) out_status[frame] = status;
-      if (out_aabb) {
-        float *a = out_aabb + 6 * (int64_t)frame;
-        a[0] = ab.mn[0]; a[1] = ab.mn[1]; a[2] = ab.mn[2];
-        a[3] = ab.mx[0]; a[4] = ab.mx[1]; a[5] = ab.mx[2];
-      }
-      if (out_grid) {
-        float *q = out_grid + 8 * (int64_t)frame;
-        q[0] = g.mid[0]; q[1] = g.mid[1]; q[2] = g.mid[2];
-        q[3] = g.max_l; q[4] = g.voxel_len; q[5] = g.trunc; q[6] = 0.f; q[7] = 0.f;
-      }
-      if (out_ori) {
-        float *q = out_ori + 3 * (int64_t)frame;
-        q[0] = g.ori[0]; q[1] = g.ori[1]; q[2] = g.ori[2];
-      }
-    }
+    if (gtid == 0) write_frame_outputs(a, frame, g, ab, status);
+    write_labels(a, frame, g, status, xf, gtid, kGW);
 
-    bool ran_phase2 = false;
+    // the frame's spans are in the pool iff capture was on and every row fitted (group-uniform: the flag
+    // was written before the extents barrier)
+    bool captured = cap.on && lds_load(&ctl.cap_fail[group]) == 0;
+    captured = __builtin_amdgcn_readfirstlane(captured);
+
     if (want_vol) {
       if (status != TSDF_FRAME_OK) {
-        zero_volume(out, R, gtid);
+        zero_volume(out, R, gtid, kGW, 0, 1);
+        if constexpr (DBG) {
+          if (a.pixmap)
+            for (int i = gtid; i < R * R * R; i += kGW) a.pixmap[(int64_t)frame * R * R * R + i] = -1;
+        }
       } else {
-        ran_phase2 = true;
         // The thread's index for the tables and the voxel pass, hidden from loop-invariant code motion:
         // otherwise every constant derived from it (a dozen float64 conversions of voxel indices) is
         // computed once before the frame loop and then occupies registers, or scratch, all through phase 1.
         int vt = gtid;
         asm volatile("" : "+v"(vt));
-        VoxK vk;
-        vk.cx = cam.cx;
-        vk.cy = cam.cy;
-        vk.it = 1.0 / (double)g.trunc;
-        vk.kq = cam.inv_focal * vk.it;
-        vk.ncx = -cam.cx;
-        vk.eps = cam.eps;
-        vk.px0 = f.l + ab.c0;
-        vk.py0 = f.t + ab.r0;
-        vk.dx = ab.c1 - ab.c0;
-        vk.dy = ab.r1 - ab.r0;
-        // LDS image of the rectangle: rows padded to a multiple of 4 pixels (16-byte LDS-DMA pieces)
-        const int sw = vk.dx + 1, sh = vk.dy + 1;
-        const int sw4 = (sw + 3) & ~3;
-        const bool staged = (int64_t)sw4 * sh <= kStageFloats;  // group-uniform
-
-        // ---- stage the rectangle of valid pixels into LDS by LDS-DMA (global_load_lds_dwordx4) ----
+        // ---- TSDF_FILL 0: stage the valid pixels' rectangle into the pool by LDS-DMA (global_load_lds_dwordx4) ----
         // No VGPR staging and no ds_write pass: each wave instruction moves up to 64 x 16 B straight into
         // the row-major LDS image (lane i lands at base + 16*i, so lanes are laid out as [row][4-pixel
         // group]); all of a wave's pieces are in flight at once.  Sources need only 4-byte alignment
-        // and EXEC-masked lanes leave their slot untouched (tools/probes/glds_probe.hip).
+        // and EXEC-masked lanes leave their slot untouched (tools/probes/glds_probe.hip).  The group holds
+        // the pool lock here (taken at the extents barrier), so the whole pool is its own.
+        int mode = captured ? kFillSpans : kFillGlobal;
+        // the staged image: the rectangle of valid pixels (the whole bounding box in the diagnostic build),
+        // row-major from the start of the pool, rows padded to a multiple of 4 pixels (16-byte DMA pieces)
+        const int sc0 = DBG ? 0 : ab.c0, sr0 = DBG ? 0 : ab.r0;
+        const int sw = DBG ? f.bw : ab.c1 - ab.c0 + 1, sh = DBG ? f.bh : ab.r1 - ab.r0 + 1;
+        const int sw4 = (sw + 3) & ~3;
+        const bool staged = !kCaptureFill && (int64_t)sw4 * sh <= L::kPoolFloats;  // group-uniform
         if (staged) {
+          mode = kFillRect;
+          float *stage = lds.pool;
           const int ng = sw4 >> 2;                       // 4-pixel groups per row
           const int64_t n_frame = fh.off1 - fh.off0;     // elements in this frame's crop
-          const int64_t base_idx = (int64_t)ab.r0 * f.bw + ab.c0;
+          const int64_t base_idx = (int64_t)sr0 * f.bw + sc0;
           if (ng <= 64) {
             const int rows_per = 64 / ng;                // rows one wave instruction covers
             const int rsub = lane / ng, cg = lane - rsub * ng;
@@ -1145,41 +1587,12 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
             }
           }
         }
-        // ---- per-frame tables (true divisions; (x,z)/(y,z) pairs spread over the group) ----
-        const double vl = (double)g.voxel_len;
-        const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
-        TSDF_STAMP(kGroups * iter + group, 5);
-        if (vt < R) {
-          const double v_z = oz + (double)vt * vl;  // :28
-          ZEntry ze;
-          ze.q = -cam.focal / v_z;                    // :30
-          ze.vzs = v_z * vk.it;
-          ze.negthr = f32_round_up(-v_z);             // pd < -v_z  <=>  w_z > v_z  (:65)
-          ze.pad = 0.f;
-          ztab[vt] = ze;
-        }
-        if constexpr (AUG) {
-          // products of the inverse map, one per (axis, index, row): see phase2_aug
-          const double *inv = xforms + 24 * (int64_t)frame + 12;
-          for (int e = vt; e < 9 * R; e += kGW) {
-            const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
-            const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
-            atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
-          }
-        }
+        const VoxK vk = make_voxk(cam, g, f, ab, mode, DBG, sw4);
         const bool use_tab = !AUG && R <= kTabR;  // uniform
-        if (use_tab) {
-          for (int e = vt; e < R * R; e += kGW) {
-            const int z = e / R, i = e - z * R;
-            const double q = -cam.focal / (oz + (double)z * vl);                              // :30
-            const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
-            pxtab[tab_index<LAYOUT>(i, z, R)] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);    // :31
-            pytab[tab_index<LAYOUT>(i, z, R)] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);   // :32
-          }
-        }
+        TSDF_STAMP(kGroups * iter + group, 5);
+        fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, mode == kFillSpans, xf, vt, kGW);
         TSDF_STAMP(kGroups * iter + group, 6);
-
-        // the copy was issued before the tables were computed (worth 1.1 % of the launch, tools/ab_precise.py)
+        // the copy was issued before the tables were computed (worth 1.1 % of the launch, round 1)
         if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is counted in vmcnt
         TSDF_STAMP(kGroups * iter + group, 7);
         if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
@@ -1187,8 +1600,6 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
         }
         gsync();
         TSDF_STAMP(kGroups * iter + group, 8);
-        vk.stride = staged ? sw4 : f.bw;
-        vk.base = staged ? 0 : ab.r0 * f.bw + ab.c0;
         bool helped = false;  // group-uniform
         if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
           // the other group is idle (so this is the launch's last frame on this CU): split the volume with it
@@ -1199,46 +1610,56 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
               hq.g = g;
               hq.vk = vk;
               hq.src = f.depth;
-              hq.staged = staged;
-              hq.pad = 0;
+              hq.mode = mode;
+              hq.owner = group;
               hq.out = out;
               hq.frame = frame;
               hq.use_tab = use_tab;
+              hq.pm_bw = f.bw;
+              hq.pm_dc = vk.px0 - f.l;
+              hq.pm_dr = vk.py0 - f.t;
+              hq.pad = 0;
               ctl.help = hq;
               lds_store(&ctl.help_for, (group ^ 1) + 1);
             }
           }
         }
         TSDF_STAMP_VAL(kGroups * iter + group, 10, helped ? 2 : 1);
+        const Tabs tb = make_tabs(pg);
+        PixMapK pm;
+        pm.out = DBG && a.pixmap ? (GlobalPix)(a.pixmap + (int64_t)frame * R * R * R) : (GlobalPix) nullptr;
+        pm.bw = f.bw;
+        pm.dc = vk.px0 - f.l;
+        pm.dr = vk.py0 - f.t;
         auto run2 = [&](auto src) {
           if (__builtin_expect(helped, 0)) {
             if constexpr (AUG) {
-              phase2_aug<LAYOUT, 2 * kGW>(g, cam, vk, R, xforms + 24 * (int64_t)frame, atab, src, (GlobalOut)out, vt);
+              phase2_aug<LAYOUT, 2 * kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
             } else {
-              phase2<LAYOUT, 2 * kGW>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, src, (GlobalOut)out, vt);
+              phase2<LAYOUT, 2 * kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
             }
           } else {
             if constexpr (AUG) {
-              phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xforms + 24 * (int64_t)frame, atab, src, (GlobalOut)out, vt);
+              phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
             } else {
-              phase2<LAYOUT, kGW>(g, cam, vk, R, ztab, pxtab, pytab, use_tab, src, (GlobalOut)out, vt);
+              phase2<LAYOUT, kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
             }
           }
         };
-        if (staged) {
-          run2((LdsSrc)stage);
+        if (mode == kFillRect) {
+          run2(LdsRect{(LdsSrc)lds.pool});
+        } else if (mode == kFillSpans) {
+          run2((LdsSrc)lds.pool);
         } else {
           run2((GlobalSrc)f.depth);
         }
       }
     }
     TSDF_STAMP(kGroups * iter + group, 9);
-    // Close the frame: every wave of the group has left the LDS it shares (stage/tables when phase 2
-    // ran, `red` and the header mailbox always) before the lock is handed over and the next frame
-    // rewrites them.
+    // Close the frame: every wave of the group has left the LDS it shares (pool spans, tables, `red`, the
+    // header mailbox) before the next frame rewrites them.
     gsync();
-    (void)ran_phase2;
-    if (holds_stage && gwave == 0 && lane == 0)
+    if (holds_lock && gwave == 0 && lane == 0)
       __hip_atomic_store(&ctl.lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   // ---- queue empty: offer help with the other group's last frame before leaving ----
@@ -1263,30 +1684,155 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(
       // them is a FLAT instruction (counted in lgkmcnt as well as vmcnt)
       const GlobalOut hout = (GlobalOut)hq.out;
       const GlobalSrc hsrc = (GlobalSrc)hq.src;
+      const Tabs tb = make_tabs(lds.pg[group ^ 1]);  // the owner's tables
+      PixMapK pm;
+      pm.out = DBG && a.pixmap ? (GlobalPix)(a.pixmap + (int64_t)hq.frame * R * R * R) : (GlobalPix) nullptr;
+      pm.bw = hq.pm_bw;
+      pm.dc = hq.pm_dc;
+      pm.dr = hq.pm_dr;
       auto run2 = [&](auto src) {
         if constexpr (AUG) {
-          phase2_aug<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, xforms + 24 * (int64_t)hq.frame, atab, src, hout,
-                                      kGW + gtid);
+          phase2_aug<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, a.xforms + 24 * (int64_t)hq.frame, tb, src, hout,
+                                      kGW + gtid, 0, R);
         } else {
-          phase2<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, ztab, pxtab, pytab, hq.use_tab != 0, src, hout, kGW + gtid);
+          phase2<LAYOUT, 2 * kGW, DBG>(hq.g, cam, hq.vk, R, tb, hq.use_tab != 0, src, hout, kGW + gtid, 0, R, pm);
         }
       };
-      if (hq.staged) {
-        run2((LdsSrc)stage);
+      if (hq.mode == kFillRect) {
+        run2(LdsRect{(LdsSrc)lds.pool});
+      } else if (hq.mode == kFillSpans) {
+        run2((LdsSrc)lds.pool);
       } else {
         run2(hsrc);
       }
     }
   }
-  // ---- leave: the last group of the launch returns the queue slot to its initial state ----
-  if (gwave == 0 && lane == 0) {
-    const unsigned int d = atomicAdd(q_done, 1u);
-    if (d + 1 == (unsigned int)(gridDim.x * kGroups)) {
-      __hip_atomic_store(q_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(q_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Split kernel for small batches (n <= CUs/2): a.split workgroups per frame.  Every workgroup streams the
+// whole frame with its 16 waves (the frame comes from L2 / Infinity Cache for all but the first), captures
+// the spans, places the grid, fills the tables — all redundantly, so no workgroup ever waits for another —
+// and voxelizes a.per slices of the slow axis.  Results are bit-identical to the fused kernel's: the
+// extents are min/max reductions (order-free) and the per-voxel code is the same.
+template <int RT, int LAYOUT, bool AUG>
+__global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a) {
+  using L = Lds<RT, AUG>;
+  __shared__ typename L::Block lds;
+
+  const int R = RT ? RT : a.R;
+  const CamK &cam = a.cam;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frame = blockIdx.x / a.split, part = blockIdx.x - frame * a.split;
+  auto &pg = lds.pg[0];
+  GroupCtl &ctl = lds.ctl;
+  if (tid == 0) ctl.cap_fail[0] = 0;
+  FrameHdr fh;
+  {
+    const int32_t *h = a.headers + 6 * (int64_t)frame;  // uniform: scalar loads
+    fh.frame = frame;
+    fh.l = h[2];
+    fh.t = h[3];
+    fh.r = h[4];
+    fh.b = h[5];
+    fh.pad = 0;
+    fh.off0 = a.offsets[frame];
+    fh.off1 = a.offsets[frame + 1];
+  }
+  __syncthreads();
+  Frame f;
+  const bool hdr_ok = frame_from_header(fh, a.depth, a.depth_len, f);
+  float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
+  const bool want_vol = !a.aabb_only && out;
+
+  int status = TSDF_FRAME_OK;
+  Aabb ab;
+  ab.any = false;
+  ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+  ab.c0 = ab.r0 = 0;
+  ab.c1 = ab.r1 = -1;
+  Grid g;
+  g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
+  g.max_l = g.voxel_len = g.trunc = 0.f;
+  g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
+  const double *xf = AUG ? a.xforms + 24 * (int64_t)frame : nullptr;
+
+  Capture cap;
+  cap.pool = (LdsF)lds.pool;
+  cap.rowtab = (LdsU)pg.rowtab;
+  cap.fail = (LdsI)&ctl.cap_fail[0];
+  cap.cap4 = L::kPoolUnits / (kWG / 64);
+  cap.base4 = wave * cap.cap4;
+  cap.on = false;
+  if (!hdr_ok) {
+    status = TSDF_FRAME_BAD_HEADER;
+  } else {
+    float fin[kExt];
+    cap.on = want_vol && f.bw <= kMaxCapW && f.bh <= kMaxRows;
+    auto sync_all = [&]() { __syncthreads(); };
+    phase1_extents<kWG / 64, AUG, true>(f, cam, 0, f.bh, pg.red, fin, wave, sync_all, cap, 0, xf);
+    ab = aabb_from_extents(fin);
+    place_grid(ab, R, cam, a.grid_in, frame, g, status);
+  }
+  if (part == 0) {
+    if (tid == 0) write_frame_outputs(a, frame, g, ab, status);
+    write_labels(a, frame, g, status, xf, tid, kWG);
+  }
+  if (!want_vol) return;
+  if (status != TSDF_FRAME_OK) {
+    zero_volume(out, R, tid, kWG, part, a.split);
+    return;
+  }
+  bool captured = cap.on && lds_load(&ctl.cap_fail[0]) == 0;
+  captured = __builtin_amdgcn_readfirstlane(captured);
+  const VoxK vk = make_voxk(cam, g, f, ab, captured ? kFillSpans : kFillGlobal, false, 0);
+  const bool use_tab = !AUG && R <= kTabR;
+  fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, captured, xf, tid, kWG);
+  __syncthreads();
+  const Tabs tb = make_tabs(pg);
+  const int sb = part * a.per, se = sb + a.per < R ? sb + a.per : R;
+  PixMapK pm;
+  pm.out = (GlobalPix) nullptr;
+  pm.bw = f.bw;
+  pm.dc = pm.dr = 0;
+  auto run2 = [&](auto src) {
+    if constexpr (AUG) {
+      phase2_aug<LAYOUT, kWG>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, tid, sb, se);
+    } else {
+      phase2<LAYOUT, kWG, false>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, tid, sb, se, pm);
     }
+  };
+  if (captured) {
+    run2((LdsSrc)lds.pool);
+  } else {
+    run2((GlobalSrc)f.depth);
   }
 }
+
+// Label normalisation on its own (pre/joint_nor.py:8-18) and its inverse (3D_CNN/train.py:263-266).
+__global__ void tsdf_normalize_kernel(const float *__restrict__ gt, const float *__restrict__ max_l,
+                                      const float *__restrict__ mid_p, int64_t total, int nc, int clamp, int inverse,
+                                      float *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t frame = e / nc;
+  const int c = (int)(e - frame * nc) % 3;
+  const float ml = max_l[frame], m = mid_p[3 * frame + c], v = gt[e];
+  float o;
+  if (inverse) {
+    o = ml > 0.f ? __fadd_rn(__fmul_rn(__fsub_rn(v, 0.5f), ml), m) : m;
+  } else if (ml > 0.f) {
+    o = __fadd_rn(__fdiv_rn(__fsub_rn(v, m), ml), 0.5f);
+    if (clamp) {
+      o = o < 0.f ? 0.f : o;
+      o = o > 1.f ? 1.f : o;
+    }
+  } else {
+    o = 0.5f;
+  }
+  out[e] = o;
+}
+
 
 const tsdf_cam kDefaultCam = {241.42, 160.0, 120.0, 1.0f, 3.0f};
 
@@ -1305,13 +1851,14 @@ int num_cus() {
 
 // The code object holds gfx950 kernels only: any other device is "no usable device", not a launch error.
 // (Cached per device id; a racing first call computes the same value.)
-int check_device() {
+int check_device(int *dev_out) {
   static int arch_state[64] = {0};  // 0 unknown, 1 gfx950, -1 something else
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return TSDF_ERR_NO_DEVICE;
   }
+  *dev_out = dev;
   if (dev < 0 || dev >= 64) return TSDF_OK;  // beyond the cache: let the launch decide
   if (arch_state[dev] == 0) {
     hipDeviceProp_t prop;
@@ -1324,86 +1871,207 @@ int check_device() {
   return arch_state[dev] == 1 ? TSDF_OK : TSDF_ERR_NO_DEVICE;
 }
 
-// everything a launch needs, so that the dispatch over (R, layout, augmented) stays in one place
-struct LaunchArgs {
-  const float *depth;
-  const int64_t *offsets;
-  const int32_t *headers;
-  int n, R;
-  CamK ck;
-  float *tsdf, *max_l, *mid_p;
-  int32_t *status;
-  float *aabb, *grid, *ori;
-  int aabb_only;
-  const float *grid_in;
-  const double *xforms;
-  int64_t depth_len;
+// ---- work-queue words: one per (device, stream) ------------------------------------------------------
+// Launches of one stream execute in order, so a word owned by the stream is never shared by two running
+// launches, however many are in flight.  hipStreamPerThread is one handle for a different stream per thread:
+// it is keyed by the calling thread as well.  No word (null) means "use CU-local queues": a launch that is
+// being captured into a graph (its node may later run anywhere, any number of times), a device beyond the
+// table, or more live streams than words.
+struct StreamSlots {
+  std::mutex mu;
+  struct Entry {
+    bool used;
+    hipStream_t s;
+    std::thread::id tid;
+  } e[kQueueSlots];
+  int high = 0;  // entries [0, high) may be in use
+  unsigned int *base = nullptr;  // device address of g_queue on this device
 };
+StreamSlots g_slots[64];
 
-template <int RT, int LAYOUT, bool AUG>
-hipError_t launch(hipStream_t s, const LaunchArgs &a) {
-  // persistent: one workgroup per CU; with fewer than kGroups frames per CU the later groups idle
-  const int grid = a.n < num_cus() ? a.n : num_cus();
-  static std::atomic<unsigned int> launch_counter{0};
-  const int qslot = (int)(launch_counter.fetch_add(1, std::memory_order_relaxed) % kQueueSlots);
-  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG>), dim3(grid), dim3(kWG), 0, s, a.depth, a.offsets,
-                     a.headers, a.n, a.R, a.ck, a.tsdf, a.max_l, a.mid_p, a.status, a.aabb, a.grid, a.ori,
-                     a.aabb_only, a.grid_in, qslot, a.xforms, a.depth_len);
+unsigned int *queue_word(int dev, hipStream_t s, bool release) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!release) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+  }
+  StreamSlots &t = g_slots[dev];
+  const bool per_thread = s == hipStreamPerThread;
+  const std::thread::id me = per_thread ? std::this_thread::get_id() : std::thread::id();
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (!t.base) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_queue)) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    t.base = static_cast<unsigned int *>(p);
+  }
+  int free_i = -1;
+  for (int i = 0; i < t.high; ++i) {
+    if (t.e[i].used) {
+      if (t.e[i].s == s && t.e[i].tid == me) {
+        if (release) {
+          t.e[i].used = false;
+          return nullptr;
+        }
+        return t.base + i;
+      }
+    } else if (free_i < 0) {
+      free_i = i;
+    }
+  }
+  if (release) return nullptr;
+  if (free_i < 0 && t.high < kQueueSlots) free_i = t.high++;
+  if (free_i < 0) return nullptr;
+  t.e[free_i].used = true;
+  t.e[free_i].s = s;
+  t.e[free_i].tid = me;
+  return t.base + free_i;
+}
+
+// Workgroups per frame and slices per workgroup for the split kernel (0: use the fused kernel).
+void split_plan(int n, int R, int cus, int *split, int *per) {
+  *split = 0;
+  *per = R;
+  if (n * 2 > cus) return;
+  const int G = R * (R / 4);
+  const int sstep = (G <= kWG && kWG % G == 0) ? kWG / G : 1;  // slices one pass of the workgroup covers
+  const int rounds = (R + sstep - 1) / sstep;
+  int S = cus / n;
+  if (S > rounds) S = rounds;
+  if (S < 2) return;
+  const int p = ((rounds + S - 1) / S) * sstep;  // slices per workgroup
+  S = (R + p - 1) / p;
+  if (S < 2) return;
+  *split = S;
+  *per = p;
+}
+
+template <int RT, int LAYOUT, bool AUG, bool DBG>
+hipError_t launch(hipStream_t s, KArgs &a, int dev) {
+  const int cus = num_cus();
+  if constexpr (!DBG) {
+    int S = 0, per = a.R;
+    if (!a.aabb_only && a.tsdf) split_plan(a.n, a.R, cus, &S, &per);
+    if (S >= 2) {
+      a.split = S;
+      a.per = per;
+      a.queue = nullptr;
+      hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG>), dim3(a.n * S), dim3(kWG), 0, s, a);
+      return hipGetLastError();
+    }
+  }
+  // persistent: one workgroup per CU; with fewer than kGroups frames per CU the later groups idle or help
+  const int grid = a.n < cus ? a.n : cus;
+  a.split = 0;
+  a.per = a.R;
+  a.queue = a.n > grid * kGroups ? queue_word(dev, s, false) : nullptr;  // no dynamic frames: no word needed
+  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a);
   return hipGetLastError();
 }
 
 template <int LAYOUT, bool AUG>
-hipError_t launch_r(hipStream_t s, const LaunchArgs &a) {
-  if (a.R == 32) return launch<32, LAYOUT, AUG>(s, a);
-  if (a.R == 64) return launch<64, LAYOUT, AUG>(s, a);
-  return launch<0, LAYOUT, AUG>(s, a);
+hipError_t launch_r(hipStream_t s, KArgs &a, int dev) {
+  if (a.R == 32) return launch<32, LAYOUT, AUG, false>(s, a, dev);
+  if (a.R == 64) return launch<64, LAYOUT, AUG, false>(s, a, dev);
+  return launch<0, LAYOUT, AUG, false>(s, a, dev);
 }
+
+struct RunOpts {
+  float *aabb = nullptr, *grid = nullptr, *ori = nullptr;
+  int aabb_only = 0;
+  const float *grid_in = nullptr;
+  const double *xforms = nullptr;
+  const tsdf_labels *labels = nullptr;
+  int32_t *pixmap = nullptr;
+};
 
 int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
         const tsdf_cam *cam, int layout, void *hip_stream, float *t, float *ml, float *mp, int32_t *st,
-        float *ab, float *gr, float *orr, int aabb_only, const float *gin = nullptr,
-        const double *xforms = nullptr) {
+        const RunOpts &o) {
   if (n < 0 || !tsdf_resolution_supported(R)) return TSDF_ERR_INVALID_ARG;
   if (layout != TSDF_LAYOUT_CZYX && layout != TSDF_LAYOUT_CXYZ) return TSDF_ERR_INVALID_ARG;
+  if (o.labels) {
+    const tsdf_labels *lb = o.labels;
+    if (lb->n_joints < 1 || lb->n_joints > 170) return TSDF_ERR_INVALID_ARG;
+    if (n > 0 && (!lb->d_gt || !lb->d_out_gt_nor)) return TSDF_ERR_INVALID_ARG;
+  }
   if (n == 0) return TSDF_OK;
   if (!d_depth || !d_offsets || !d_headers || depth_len < 0) return TSDF_ERR_INVALID_ARG;
-  if (!aabb_only && (!t || (reinterpret_cast<uintptr_t>(t) & 15))) return TSDF_ERR_INVALID_ARG;
+  if (!o.aabb_only && (!t || (reinterpret_cast<uintptr_t>(t) & 15))) return TSDF_ERR_INVALID_ARG;
   if (!cam) cam = &kDefaultCam;
   if (!(cam->focal > 0.0) || !(cam->invalid_eps > 0.0f) || !(cam->trunc_voxels > 0.0f))
     return TSDF_ERR_INVALID_ARG;
-  int rc = check_device();
+  int dev = 0;
+  int rc = check_device(&dev);
   if (rc != TSDF_OK) return rc;
-  LaunchArgs a;
+  KArgs a;
+  memset(&a, 0, sizeof a);
   a.depth = d_depth;
   a.offsets = d_offsets;
   a.headers = d_headers;
   a.n = n;
   a.R = R;
-  a.ck.focal = cam->focal;
-  a.ck.cx = cam->cx;
-  a.ck.cy = cam->cy;
-  a.ck.inv_focal = 1.0 / cam->focal;
-  a.ck.eps = cam->invalid_eps;
-  a.ck.trunc_vox = cam->trunc_voxels;
+  a.cam.focal = cam->focal;
+  a.cam.cx = cam->cx;
+  a.cam.cy = cam->cy;
+  a.cam.inv_focal = 1.0 / cam->focal;
+  a.cam.eps = cam->invalid_eps;
+  a.cam.trunc_vox = cam->trunc_voxels;
   a.tsdf = t;
   a.max_l = ml;
   a.mid_p = mp;
   a.status = st;
-  a.aabb = ab;
-  a.grid = gr;
-  a.ori = orr;
-  a.aabb_only = aabb_only;
-  a.grid_in = gin;
-  a.xforms = xforms;
+  a.aabb = o.aabb;
+  a.grid = o.grid;
+  a.ori = o.ori;
+  a.aabb_only = o.aabb_only;
+  a.grid_in = o.grid_in;
+  a.xforms = o.xforms;
   a.depth_len = depth_len;
+  if (o.labels) {
+    a.gt = o.labels->d_gt;
+    a.gt_nor = o.labels->d_out_gt_nor;
+    a.gt_aug = o.xforms ? o.labels->d_out_gt_aug : nullptr;
+    a.n_joints = o.labels->n_joints;
+    a.clamp = o.labels->clamp;
+  }
+  a.pixmap = o.pixmap;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipError_t e;
-  if (xforms) {
-    e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, true>(s, a) : launch_r<1, true>(s, a);
+  if (o.pixmap) {
+    if (layout == TSDF_LAYOUT_CZYX)
+      e = R == 32 ? launch<32, 0, false, true>(s, a, dev) : launch<0, 0, false, true>(s, a, dev);
+    else
+      e = R == 32 ? launch<32, 1, false, true>(s, a, dev) : launch<0, 1, false, true>(s, a, dev);
+  } else if (o.xforms) {
+    e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, true>(s, a, dev) : launch_r<1, true>(s, a, dev);
   } else {
-    e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, false>(s, a) : launch_r<1, false>(s, a);
+    e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, false>(s, a, dev) : launch_r<1, false>(s, a, dev);
   }
   return e == hipSuccess ? TSDF_OK : TSDF_ERR_LAUNCH;
+}
+
+int run_normalize(const float *d_in, const float *d_max_l, const float *d_mid_p, int n, int n_joints, int clamp,
+                  int inverse, void *hip_stream, float *d_out) {
+  if (n < 0 || n_joints < 1 || n_joints > 170) return TSDF_ERR_INVALID_ARG;
+  if (n == 0) return TSDF_OK;
+  if (!d_in || !d_max_l || !d_mid_p || !d_out) return TSDF_ERR_INVALID_ARG;
+  int dev = 0;
+  int rc = check_device(&dev);
+  if (rc != TSDF_OK) return rc;
+  const int nc = 3 * n_joints;
+  const int64_t total = (int64_t)n * nc;
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffff) return TSDF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(tsdf_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     d_in, d_max_l, d_mid_p, total, nc, clamp, inverse, d_out);
+  return hipGetLastError() == hipSuccess ? TSDF_OK : TSDF_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -1433,15 +2101,28 @@ int tsdf_voxelize_hip(const float *d_depth, int64_t depth_len, const int64_t *d_
                       float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status) {
   if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p)) return TSDF_ERR_INVALID_ARG;
   return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
-             d_out_mid_p, d_out_status, nullptr, nullptr, nullptr, 0);
+             d_out_mid_p, d_out_status, RunOpts{});
+}
+
+int tsdf_voxelize_labels_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
+                             int n, int R, const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf,
+                             float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels) {
+  if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p)) return TSDF_ERR_INVALID_ARG;
+  if (!labels) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.labels = labels;
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+             d_out_mid_p, d_out_status, o);
 }
 
 int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                            int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
                            float *d_out_tsdf, int32_t *d_out_status) {
   if (n > 0 && (!d_out_tsdf || !d_grid)) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.grid_in = d_grid;
   return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, nullptr, nullptr,
-             d_out_status, nullptr, nullptr, nullptr, 0, d_grid);
+             d_out_status, o);
 }
 
 int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
@@ -1449,15 +2130,66 @@ int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t
                           float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status) {
   if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !d_xforms)) return TSDF_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(d_xforms) & 7) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.xforms = d_xforms;
   return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
-             d_out_mid_p, d_out_status, nullptr, nullptr, nullptr, 0, nullptr, d_xforms);
+             d_out_mid_p, d_out_status, o);
+}
+
+int tsdf_voxelize_aug_labels_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                                 const int32_t *d_headers, int n, int R, const tsdf_cam *cam, int layout,
+                                 void *hip_stream, const double *d_xforms, float *d_out_tsdf, float *d_out_max_l,
+                                 float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels) {
+  if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !d_xforms)) return TSDF_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(d_xforms) & 7) || !labels) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.xforms = d_xforms;
+  o.labels = labels;
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+             d_out_mid_p, d_out_status, o);
 }
 
 int tsdf_aabb_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
                   const tsdf_cam *cam, void *hip_stream, float *d_out_aabb, float *d_out_grid,
                   float *d_out_ori, int32_t *d_out_status) {
+  RunOpts o;
+  o.aabb = d_out_aabb;
+  o.grid = d_out_grid;
+  o.ori = d_out_ori;
+  o.aabb_only = 1;
   return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, TSDF_LAYOUT_CZYX, hip_stream, nullptr, nullptr,
-             nullptr, d_out_status, d_out_aabb, d_out_grid, d_out_ori, 1);
+             nullptr, d_out_status, o);
+}
+
+int tsdf_normalize_joints_hip(const float *d_gt, const float *d_max_l, const float *d_mid_p, int n, int n_joints,
+                              int clamp, void *hip_stream, float *d_out_gt_nor) {
+  return run_normalize(d_gt, d_max_l, d_mid_p, n, n_joints, clamp, 0, hip_stream, d_out_gt_nor);
+}
+
+int tsdf_denormalize_joints_hip(const float *d_pred, const float *d_max_l, const float *d_mid_p, int n, int n_joints,
+                                void *hip_stream, float *d_out_joints) {
+  return run_normalize(d_pred, d_max_l, d_mid_p, n, n_joints, 0, 1, hip_stream, d_out_joints);
+}
+
+int tsdf_debug_pixmap_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
+                          int n, int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
+                          float *d_out_tsdf, int32_t *d_out_pixmap, int32_t *d_out_status) {
+  if (n > 0 && (!d_out_tsdf || !d_out_pixmap)) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.grid_in = d_grid;
+  o.pixmap = d_out_pixmap;
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, nullptr, nullptr,
+             d_out_status, o);
+}
+
+int tsdf_stream_release(void *hip_stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return TSDF_OK;
+  }
+  (void)queue_word(dev, static_cast<hipStream_t>(hip_stream), true);
+  return TSDF_OK;
 }
 
 #ifdef TSDF_STAMPS

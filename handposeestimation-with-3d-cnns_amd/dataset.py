@@ -25,7 +25,7 @@ import torch
 import torch.utils.data as data
 
 from . import packing
-from .voxelize import TsdfBatch, voxelize
+from .voxelize import TsdfBatch, denormalize_joints, normalize_joints, voxelize  # noqa: F401
 
 
 class MSRADepthDataset(data.Dataset):
@@ -154,21 +154,3 @@ class VoxelLoader:
             out = voxelize(depth, offsets, headers, res=self.res)
             yield out.tsdf, tgt, out.max_l, out.mid_p
         t.join()
-
-
-def normalize_joints(gt: torch.Tensor, max_l: torch.Tensor, mid_p: torch.Tensor) -> torch.Tensor:
-    """Labels into the voxel cube's [0,1] frame: ``(gt - mid_p) / max_l + 0.5`` per joint
-    (pre/joint_nor.py:8-18; the per-sample Python loop of 3D_CNN/train.py:236-244), on the GPU with
-    the voxelizer's own ``max_l`` / ``mid_p``.  gt [n,63] or [n,21,3]; result has gt's shape."""
-    shp = gt.shape
-    j = gt.reshape(shp[0], 21, 3)
-    out = (j - mid_p[:, None, :]) / max_l[:, None, None] + 0.5
-    return out.reshape(shp)
-
-
-def denormalize_joints(pred: torch.Tensor, max_l: torch.Tensor, mid_p: torch.Tensor) -> torch.Tensor:
-    """Inverse of :func:`normalize_joints` (3D_CNN/train.py:263-266)."""
-    shp = pred.shape
-    j = pred.reshape(shp[0], 21, 3)
-    out = (j - 0.5) * max_l[:, None, None] + mid_p[:, None, :]
-    return out.reshape(shp)

@@ -36,6 +36,64 @@ def _dev_check(name, t, dtype, device=None):
         raise ValueError(f"{name} is on {t.device}, expected {device}")
 
 
+def _check_inputs(L, depth, offsets, headers, res, layout):
+    """Shared validation of the packed-frame inputs; returns (device, n, R)."""
+    if layout not in _lib.LAYOUTS:
+        raise ValueError("layout must be 'czyx' or 'cxyz'")
+    _dev_check("depth", depth, torch.float32)
+    dev = depth.device
+    _dev_check("offsets", offsets, torch.int64, dev)
+    _dev_check("headers", headers, torch.int32, dev)
+    if headers.dim() != 2 or headers.shape[1] != 6:
+        raise ValueError("headers must have shape [n, 6]")
+    n = headers.shape[0]
+    if offsets.numel() != n + 1:
+        raise ValueError("offsets must have n+1 entries")
+    if not L.tsdf_resolution_supported(int(res)):
+        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
+    return dev, n, int(res)
+
+
+def _make_out(out, n, R, dev) -> "TsdfBatch":
+    """Allocate the outputs, or validate caller-supplied ones (device, dtype, contiguity, shape): their
+    data pointers go straight to the kernel."""
+    if out is None:
+        return TsdfBatch(
+            torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev),
+            torch.empty((n,), dtype=torch.float32, device=dev),
+            torch.empty((n, 3), dtype=torch.float32, device=dev),
+            torch.empty((n,), dtype=torch.int32, device=dev),
+        )
+    _dev_check("out.tsdf", out.tsdf, torch.float32, dev)
+    _dev_check("out.max_l", out.max_l, torch.float32, dev)
+    _dev_check("out.mid_p", out.mid_p, torch.float32, dev)
+    _dev_check("out.status", out.status, torch.int32, dev)
+    if tuple(out.tsdf.shape) != (n, 3, R, R, R) or out.max_l.numel() != n or \
+            tuple(out.mid_p.shape) != (n, 3) or out.status.numel() != n:
+        raise ValueError("out tensors have the wrong shape")
+    return out
+
+
+def _labels_struct(gt, n, dev, clamp, out_gt_nor=None, want_aug=False):
+    """Validate the label tensors and build the ``tsdf_labels`` struct (kept alive by the caller)."""
+    _dev_check("gt", gt, torch.float32, dev)
+    if gt.shape[0] != n or gt.numel() % (3 * max(n, 1)) != 0 and n > 0:
+        raise ValueError("gt must have shape [n, 3*J] or [n, J, 3]")
+    nc = gt.numel() // n if n else 63
+    if nc % 3 or not 1 <= nc // 3 <= 170:
+        raise ValueError("gt must hold 1..170 joints of 3 coordinates per frame")
+    if out_gt_nor is None:
+        out_gt_nor = torch.empty_like(gt)
+    else:
+        _dev_check("out_gt_nor", out_gt_nor, torch.float32, dev)
+        if out_gt_nor.shape != gt.shape:
+            raise ValueError("out_gt_nor must have gt's shape")
+    gt_aug = torch.empty_like(gt) if want_aug else None
+    lab = _lib.TsdfLabels(gt.data_ptr(), nc // 3, 1 if clamp else 0, out_gt_nor.data_ptr(),
+                          gt_aug.data_ptr() if gt_aug is not None else None)
+    return lab, out_gt_nor, gt_aug
+
+
 def voxelize(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res: int = 32,
              layout: str = "czyx", cam: Optional[_lib.TsdfCam] = None,
              out: Optional[TsdfBatch] = None) -> TsdfBatch:
@@ -51,35 +109,8 @@ def voxelize(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, 
     Enqueues on ``torch.cuda.current_stream()`` and returns without synchronising.
     """
     L = _lib.load()
-    if layout not in _lib.LAYOUTS:
-        raise ValueError("layout must be 'czyx' or 'cxyz'")
-    _dev_check("depth", depth, torch.float32)
-    dev = depth.device
-    _dev_check("offsets", offsets, torch.int64, dev)
-    _dev_check("headers", headers, torch.int32, dev)
-    if headers.dim() != 2 or headers.shape[1] != 6:
-        raise ValueError("headers must have shape [n, 6]")
-    n = headers.shape[0]
-    if offsets.numel() != n + 1:
-        raise ValueError("offsets must have n+1 entries")
-    if not L.tsdf_resolution_supported(int(res)):
-        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
-    R = int(res)
-    if out is None:
-        out = TsdfBatch(
-            torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev),
-            torch.empty((n,), dtype=torch.float32, device=dev),
-            torch.empty((n, 3), dtype=torch.float32, device=dev),
-            torch.empty((n,), dtype=torch.int32, device=dev),
-        )
-    else:
-        _dev_check("out.tsdf", out.tsdf, torch.float32, dev)
-        _dev_check("out.max_l", out.max_l, torch.float32, dev)
-        _dev_check("out.mid_p", out.mid_p, torch.float32, dev)
-        _dev_check("out.status", out.status, torch.int32, dev)
-        if tuple(out.tsdf.shape) != (n, 3, R, R, R) or out.max_l.numel() != n or \
-                tuple(out.mid_p.shape) != (n, 3) or out.status.numel() != n:
-            raise ValueError("out tensors have the wrong shape")
+    dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
+    out = _make_out(out, n, R, dev)
     if n == 0:
         return out
     with torch.cuda.device(dev):
@@ -90,6 +121,106 @@ def voxelize(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, 
                                  out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())
     _lib.check(rc, "tsdf_voxelize_hip")
     return out
+
+
+def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, gt: torch.Tensor,
+                    res: int = 32, layout: str = "czyx", cam: Optional[_lib.TsdfCam] = None, clamp: bool = True,
+                    out: Optional[TsdfBatch] = None, out_gt_nor: Optional[torch.Tensor] = None):
+    """:func:`voxelize` plus the label normalisation of the same launch: ``(gt - mid_p) / max_l + 0.5`` per
+    joint coordinate (pre/joint_nor.py:8-18), clamped to [0,1] as 3D_CNN/train.py:241-242 does (``clamp``).
+    gt float32[n,63] (or [n,J,3]) on the GPU.  Returns ``(TsdfBatch, gt_nor)``; frames whose status is not 0
+    get 0.5 everywhere."""
+    L = _lib.load()
+    dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
+    out = _make_out(out, n, R, dev)
+    lab, gt_nor, _ = _labels_struct(gt, n, dev, clamp, out_gt_nor)
+    if n == 0:
+        return out, gt_nor
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.tsdf_voxelize_labels_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
+                                        ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], stream,
+                                        out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(),
+                                        out.status.data_ptr(), ctypes.byref(lab))
+    _lib.check(rc, "tsdf_voxelize_labels_hip")
+    return out, gt_nor
+
+
+def normalize_joints(gt: torch.Tensor, max_l: torch.Tensor, mid_p: torch.Tensor, clamp: bool = True,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Labels into the voxel cube's [0,1] frame on their own (``tsdf_normalize_joints_hip``):
+    ``(gt - mid_p) / max_l + 0.5`` (pre/joint_nor.py:8-18), clamped as 3D_CNN/train.py:241-242 unless
+    ``clamp=False``; frames with ``max_l == 0`` give 0.5.  gt [n,63] or [n,21,3]; result has gt's shape."""
+    return _norm_call(gt, max_l, mid_p, clamp, False, out)
+
+
+def denormalize_joints(pred: torch.Tensor, max_l: torch.Tensor, mid_p: torch.Tensor,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inverse of :func:`normalize_joints` for network outputs: ``(pred - 0.5) * max_l + mid_p``
+    (3D_CNN/train.py:263-266)."""
+    return _norm_call(pred, max_l, mid_p, False, True, out)
+
+
+def _norm_call(x, max_l, mid_p, clamp, inverse, out):
+    L = _lib.load()
+    _dev_check("joints", x, torch.float32)
+    dev = x.device
+    n = x.shape[0]
+    _dev_check("max_l", max_l, torch.float32, dev)
+    _dev_check("mid_p", mid_p, torch.float32, dev)
+    if max_l.numel() != n or tuple(mid_p.shape) != (n, 3):
+        raise ValueError("max_l must be [n] and mid_p [n,3]")
+    nc = x.numel() // n if n else 63
+    if n and (x.numel() != n * nc or nc % 3 or not 1 <= nc // 3 <= 170):
+        raise ValueError("joints must have shape [n, 3*J] or [n, J, 3]")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _dev_check("out", out, torch.float32, dev)
+        if out.shape != x.shape:
+            raise ValueError("out must have the input's shape")
+    if n:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if inverse:
+                rc = L.tsdf_denormalize_joints_hip(x.data_ptr(), max_l.data_ptr(), mid_p.data_ptr(), n, nc // 3,
+                                                   stream, out.data_ptr())
+            else:
+                rc = L.tsdf_normalize_joints_hip(x.data_ptr(), max_l.data_ptr(), mid_p.data_ptr(), n, nc // 3,
+                                                 1 if clamp else 0, stream, out.data_ptr())
+        _lib.check(rc, "tsdf_(de)normalize_joints_hip")
+    return out
+
+
+def release_stream(stream=None) -> None:
+    """Tell the library that ``stream`` (default: the current one) is going away (``tsdf_stream_release``)."""
+    L = _lib.load()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    L.tsdf_stream_release(s.cuda_stream)
+
+
+def voxel_pixels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res: int = 32,
+                 layout: str = "czyx", grid: Optional[torch.Tensor] = None, cam: Optional[_lib.TsdfCam] = None):
+    """Diagnostic (``tsdf_debug_pixmap_hip``): the voxelizer together with the pixel every voxel gathers.
+    Returns ``(tsdf, pixmap int32[n,R,R,R] indexed [z,y,x], status)``; pixmap values as in include/tsdf.h."""
+    L = _lib.load()
+    dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
+    if grid is not None:
+        _dev_check("grid", grid, torch.float32, dev)
+        if tuple(grid.shape) != (n, 8):
+            raise ValueError("grid must have shape [n, 8]")
+    tsdf = torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev)
+    pm = torch.empty((n, R, R, R), dtype=torch.int32, device=dev)
+    st = torch.empty((n,), dtype=torch.int32, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.tsdf_debug_pixmap_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
+                                         ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], stream,
+                                         grid.data_ptr() if grid is not None else None, tsdf.data_ptr(),
+                                         pm.data_ptr(), st.data_ptr())
+        _lib.check(rc, "tsdf_debug_pixmap_hip")
+    return tsdf, pm, st
 
 
 class AabbBatch(NamedTuple):
@@ -107,9 +238,13 @@ def aabb(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res:
     dev = depth.device
     _dev_check("offsets", offsets, torch.int64, dev)
     _dev_check("headers", headers, torch.int32, dev)
+    if headers.dim() != 2 or headers.shape[1] != 6:
+        raise ValueError("headers must have shape [n, 6]")
     n = headers.shape[0]
     if offsets.numel() != n + 1:
         raise ValueError("offsets must have n+1 entries")
+    if not L.tsdf_resolution_supported(int(res)):
+        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
     ab = torch.empty((n, 6), dtype=torch.float32, device=dev)
     grid = torch.empty((n, 8), dtype=torch.float32, device=dev)
     ori = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -133,19 +268,10 @@ def voxelize_grid(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Ten
     Returns (tsdf float32[n,3,R,R,R], status int32[n]).
     """
     L = _lib.load()
-    if layout not in _lib.LAYOUTS:
-        raise ValueError("layout must be 'czyx' or 'cxyz'")
-    _dev_check("depth", depth, torch.float32)
-    dev = depth.device
-    _dev_check("offsets", offsets, torch.int64, dev)
-    _dev_check("headers", headers, torch.int32, dev)
+    dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
     _dev_check("grid", grid, torch.float32, dev)
-    n = headers.shape[0]
-    if offsets.numel() != n + 1 or tuple(grid.shape) != (n, 8):
-        raise ValueError("offsets must have n+1 entries and grid shape [n, 8]")
-    if not L.tsdf_resolution_supported(int(res)):
-        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
-    R = int(res)
+    if tuple(grid.shape) != (n, 8):
+        raise ValueError("grid must have shape [n, 8]")
     tsdf = torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev)
     st = torch.empty((n,), dtype=torch.int32, device=dev)
     if n:
@@ -161,43 +287,35 @@ def voxelize_grid(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Ten
 
 def voxelize_aug(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, xforms: torch.Tensor,
                  res: int = 64, layout: str = "czyx", cam: Optional[_lib.TsdfCam] = None,
-                 out: Optional[TsdfBatch] = None) -> TsdfBatch:
+                 out: Optional[TsdfBatch] = None, gt: Optional[torch.Tensor] = None, clamp: bool = True):
     """Voxelization with a per-frame 3-D affine augmentation fused into the kernel
     (BASELINE.json configs[4]; see ``tsdf_voxelize_aug_hip`` in include/tsdf.h for the contract).
 
     xforms  float64[n,24] on the GPU: forward map rows {A_i0,A_i1,A_i2,b_i} then the inverse map
             (``augment.random_affines`` / ``augment.pack_affine`` build them).
-    Returns the same TsdfBatch as :func:`voxelize`; ``max_l`` / ``mid_p`` are in the mapped frame.
+    gt      optional float32[n,63] labels: they are mapped with the frame's forward map and normalised in the
+            augmented grid by the same launch (``tsdf_voxelize_aug_labels_hip``).
+    Returns the same TsdfBatch as :func:`voxelize` (``max_l`` / ``mid_p`` in the mapped frame), or
+    ``(TsdfBatch, gt_nor, gt_aug)`` when ``gt`` is given.
     """
     L = _lib.load()
-    if layout not in _lib.LAYOUTS:
-        raise ValueError("layout must be 'czyx' or 'cxyz'")
-    _dev_check("depth", depth, torch.float32)
-    dev = depth.device
-    _dev_check("offsets", offsets, torch.int64, dev)
-    _dev_check("headers", headers, torch.int32, dev)
+    dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
     _dev_check("xforms", xforms, torch.float64, dev)
-    n = headers.shape[0]
-    if offsets.numel() != n + 1 or tuple(xforms.shape) != (n, 24):
-        raise ValueError("offsets must have n+1 entries and xforms shape [n, 24]")
-    if not L.tsdf_resolution_supported(int(res)):
-        raise ValueError(f"unsupported grid resolution {res} (multiple of 4 in 4..128)")
-    R = int(res)
-    if out is None:
-        out = TsdfBatch(
-            torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev),
-            torch.empty((n,), dtype=torch.float32, device=dev),
-            torch.empty((n, 3), dtype=torch.float32, device=dev),
-            torch.empty((n,), dtype=torch.int32, device=dev),
-        )
-    elif tuple(out.tsdf.shape) != (n, 3, R, R, R):
-        raise ValueError("out tensors have the wrong shape")
+    if tuple(xforms.shape) != (n, 24):
+        raise ValueError("xforms must have shape [n, 24]")
+    out = _make_out(out, n, R, dev)
+    lab = gt_nor = gt_aug = None
+    if gt is not None:
+        lab, gt_nor, gt_aug = _labels_struct(gt, n, dev, clamp, want_aug=True)
     if n:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.tsdf_voxelize_aug_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
-                                         ctypes.byref(cam) if cam is not None else None,
-                                         _lib.LAYOUTS[layout], stream, xforms.data_ptr(), out.tsdf.data_ptr(),
-                                         out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())
+            args = (depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
+                    ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], stream, xforms.data_ptr(),
+                    out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())
+            if lab is None:
+                rc = L.tsdf_voxelize_aug_hip(*args)
+            else:
+                rc = L.tsdf_voxelize_aug_labels_hip(*args, ctypes.byref(lab))
         _lib.check(rc, "tsdf_voxelize_aug_hip")
-    return out
+    return out if gt is None else (out, gt_nor, gt_aug)

@@ -15,10 +15,17 @@
  *   - Calls enqueue work on `hip_stream` (a hipStream_t, NULL = default stream)
  *     and return WITHOUT synchronising.  They allocate nothing, never print and
  *     never throw; they are re-entrant for distinct streams and may be captured
- *     into a hipGraph.  (Each launch takes one of 1024 device-side work-queue slots,
- *     chosen round-robin on the host and left clean by the launch itself: up to 1024
- *     launches may be in flight at once, and one captured launch must not be
- *     replayed concurrently with itself.)
+ *     into a hipGraph.  Work-queue ownership (the kernels hand frames to their
+ *     workgroups dynamically): an eager launch uses a device-side queue word owned by
+ *     its (device, stream) pair — launches on one stream execute in order, so the word
+ *     is never shared, however many launches are in flight; the library keeps one word
+ *     per stream it has seen (tsdf_stream_release returns it).  A launch issued while
+ *     its stream is being captured, on hipStreamPerThread from more threads than there
+ *     are words, or on a stream beyond the 1024th distinct one uses no global state at
+ *     all: its workgroups then share frames through a counter in their own LDS (static
+ *     split across CUs, dynamic inside a CU).  A captured launch is therefore
+ *     self-contained: it may be replayed on any stream, next to eager launches, next to
+ *     other graphs and next to itself (outputs permitting).
  *   - Return value: TSDF_OK (0) or a negative tsdf_status.  Per-frame data
  *     conditions (degenerate / malformed frames) never fail the call; they are
  *     reported through `d_out_status` and produce an all-zero volume.
@@ -34,7 +41,7 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 2
+#define TSDF_ABI_VERSION 3
 
 /* Output volume layouts.  Both hold float32[n][3][R][R][R]; channel c = x,y,z component. */
 enum tsdf_layout {
@@ -52,11 +59,13 @@ enum tsdf_status {
 /* Per-frame status words written to d_out_status (int32). */
 enum tsdf_frame_status {
   TSDF_FRAME_OK = 0,
-  TSDF_FRAME_DEGENERATE = 1, /* no valid pixel, or AABB of zero extent: zero volume, max_l = 0.
+  TSDF_FRAME_DEGENERATE = 1, /* no valid pixel, or an AABB of zero or non-finite extent / non-finite centre
+                                (a +-inf depth is "valid" by the |d| >= eps rule): zero volume, max_l = 0;
+                                mid_p as computed when finite (zero extent), else 0.
                                 The reference prints and returns None here (tsdf_numba.py:162-171). */
-  TSDF_FRAME_BAD_HEADER = 2  /* right<=left, bottom<=top, bbox area != offsets[i+1]-offsets[i], or the
-                                payload not inside [0, depth_len): zero volume, max_l = 0, mid_p = 0;
-                                depth is not read.                                                  */
+  TSDF_FRAME_BAD_HEADER = 2  /* right<=left, bottom<=top, right-left or bottom-top overflowing int32, bbox area !=
+                                offsets[i+1]-offsets[i], or the payload not inside [0, depth_len): zero volume,
+                                max_l = 0, mid_p = 0; depth is not read.                            */
 };
 
 /*
@@ -69,7 +78,9 @@ typedef struct tsdf_cam {
   double focal;        /* 241.42                                                        */
   double cx;           /* 160                                                           */
   double cy;           /* 120                                                           */
-  float invalid_eps;   /* 1.0: a pixel is valid iff |depth| >= invalid_eps (:40, :87)   */
+  float invalid_eps;   /* 1.0: a pixel is valid iff |depth| >= invalid_eps (:40, :87).  A NaN depth is INVALID
+                          here (the comparison is false); in the reference abs(NaN) < 1 is false too, which
+                          makes NaN "valid" there and poisons the frame — a deliberate deviation.           */
   float trunc_voxels;  /* 3.0: truncation distance in voxel lengths (:146)              */
 } tsdf_cam;
 
@@ -113,6 +124,14 @@ int tsdf_resolution_supported(int R);
  * Arithmetic follows the numba kernels' inferred types:
  * float32 parameters, float64 intermediates, unfused multiply-add for the pixel
  * index, float32 store.  Results match that contract to <= 1e-5 absolute.
+ * What the contract is pinned to: the reference's runnable implementation of the same formula, the CPU loop
+ * (pre/tsdf_for.py / pre/process.py), evaluated on float64-typed parameters (tests/golden).  Parity with the
+ * numba kernel AS COMPILED is unpinned: numba-CUDA goes through NVVM, whose default contracts a*b+c into an
+ * fma (which would change pix = int(v*q + c) in rare voxels), it treats NaN depth as valid, and it cannot be
+ * run here (no numba, no params.py, no CUDA).
+ * Known sub-ulp deviations at the formula's discontinuities (measure ~0, effect O(1) where hit): the three
+ * divisions by trunc_dis are multiplications by its float64 reciprocal, and dist > 1 (:54) is tested as
+ * dist^2 <= 1 without the square root — these differ from tsdf_numba.py:47-54 only for dist in (1, 1+2^-52].
  */
 int tsdf_voxelize_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
                       int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
@@ -168,6 +187,63 @@ int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t
 int tsdf_aabb_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                   int R, const tsdf_cam *cam, void *hip_stream, float *d_out_aabb,
                   float *d_out_grid, float *d_out_ori, int32_t *d_out_status);
+
+/* ---- ABI v3 additions ---------------------------------------------------------------------------- */
+
+/*
+ * Label normalisation fused into the voxelizer — replaces pre/joint_nor.py:8-18 and the per-sample Python
+ * loop of 3D_CNN/train.py:236-244: joint_nor = (joint - mid_p) / max_l + 0.5 (float32, three separately
+ * rounded operations), then, with clamp != 0, joint_nor < 0 -> 0 and > 1 -> 1 (train.py:241-242; NaN stays).
+ * The lanes that hold the frame's mid_p / max_l write it, so the labels cost no extra launch.
+ * A frame whose status is not TSDF_FRAME_OK (max_l == 0; the reference returns None for it) gets 0.5 for
+ * every coordinate — the centre of the cube — instead of a division by zero.
+ */
+typedef struct tsdf_labels {
+  const float *d_gt;   /* float32[n][3*n_joints]: x,y,z per joint, camera frame, mm (rows of joint.txt,
+                          pre/read_MSRA.py:143-152)                                                         */
+  int n_joints;        /* 21 for MSRA; 1..170                                                               */
+  int clamp;           /* 1: clamp to [0,1] (3D_CNN/train.py:241-242); 0: pre/joint_nor.py as written       */
+  float *d_out_gt_nor; /* float32[n][3*n_joints]                                                            */
+  float *d_out_gt_aug; /* tsdf_voxelize_aug_labels_hip only, may be NULL: T(joint) in mm (the joints mapped
+                          with the frame's forward map, as pre/process.py:232-249 maps them with the cloud's
+                          S and R); the normalised labels are then those of T(joint) in the augmented grid   */
+} tsdf_labels;
+
+/* tsdf_voxelize_hip + labels.  `labels` is a HOST struct of device pointers, read during the call. */
+int tsdf_voxelize_labels_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                             const int32_t *d_headers, int n, int R, const tsdf_cam *cam, int layout,
+                             void *hip_stream, float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p,
+                             int32_t *d_out_status, const tsdf_labels *labels);
+
+/* tsdf_voxelize_aug_hip + labels (joints are mapped with the frame's forward map first). */
+int tsdf_voxelize_aug_labels_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                                 const int32_t *d_headers, int n, int R, const tsdf_cam *cam, int layout,
+                                 void *hip_stream, const double *d_xforms, float *d_out_tsdf, float *d_out_max_l,
+                                 float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels);
+
+/* The normalisation on its own, from max_l / mid_p already on the device (pre/joint_nor.py:8-18), and its
+ * inverse for predictions, (pred - 0.5) * max_l + mid_p (3D_CNN/train.py:263-266).  Frames with max_l == 0:
+ * 0.5 / mid_p respectively. */
+int tsdf_normalize_joints_hip(const float *d_gt, const float *d_max_l, const float *d_mid_p, int n, int n_joints,
+                              int clamp, void *hip_stream, float *d_out_gt_nor);
+int tsdf_denormalize_joints_hip(const float *d_pred, const float *d_max_l, const float *d_mid_p, int n,
+                                int n_joints, void *hip_stream, float *d_out_joints);
+
+/*
+ * Diagnostic: the voxelizer with its pixel map.  Same kernel code path as tsdf_voxelize_hip /
+ * tsdf_voxelize_grid_hip (d_grid NULL / non-NULL) — projection tables, row-span capture, gather — with one
+ * extra store per voxel:  d_out_pixmap int32[n][R][R][R], indexed [z][y][x] whatever the layout, holds the
+ * gathered element index (pix_y - top) * b_w + pix_x - left (pre/tsdf_numba.py:38), -1 when the voxel
+ * projects outside the bounding box (:36-37), -2 - index when the pixel there is invalid (:40-41).
+ * Tests compare it exactly with the oracle's map.  Slower than the production entry (smaller LDS pool).
+ */
+int tsdf_debug_pixmap_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
+                          int n, int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
+                          float *d_out_tsdf, int32_t *d_out_pixmap, int32_t *d_out_status);
+
+/* Forget the work-queue word kept for `hip_stream` on the current device (call it when destroying a stream that
+ * has no voxelizer launch in flight; optional — an unknown stream is not an error).  Returns TSDF_OK. */
+int tsdf_stream_release(void *hip_stream);
 
 #ifdef __cplusplus
 }

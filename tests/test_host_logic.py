@@ -224,16 +224,31 @@ def test_offline_export_writes_the_reference_schema(pkg, synth, tmp_path):
             pkg.export.preprocess_tree(str(db), str(tmp_path / "r3"), device="cpu", point_clouds=False)
 
 
-def test_joint_normalisation_matches_reference_formula(pkg):
-    """(gt - mid_p) / max_l + 0.5 per joint (pre/joint_nor.py:8-18) and its inverse."""
+def test_joint_normalisation_oracle_matches_reference_formula(pkg):
+    """(gt - mid_p) / max_l + 0.5 per joint (pre/joint_nor.py:8-18) with the clamp of 3D_CNN/train.py:241-242:
+    the C oracle and the numpy restatement against the reference's own loop expression, bit for bit; the product
+    function has no CPU path."""
+    import pytest
+    import oracle
+    from oracle import tsdf_oracle_np as onp
+
     rng = np.random.default_rng(2)
-    gt = rng.normal(0, 80, (6, 63)).astype(np.float32)
+    gt = rng.normal(0, 120, (6, 63)).astype(np.float32)
     max_l = rng.uniform(150, 300, 6).astype(np.float32)
     mid_p = rng.normal(0, 50, (6, 3)).astype(np.float32)
+    max_l[4] = 0.0  # a degenerate frame: defined as 0.5 everywhere (the reference divides by zero)
     want = np.empty((6, 21, 3), np.float32)
-    for i in range(6):  # the reference's loop
-        want[i] = (gt[i].reshape(21, 3) - mid_p[i]) / max_l[i] + 0.5
-    got = pkg.normalize_joints(torch.from_numpy(gt), torch.from_numpy(max_l), torch.from_numpy(mid_p))
-    np.testing.assert_allclose(got.numpy().reshape(6, 21, 3), want, rtol=1e-6, atol=1e-6)
-    back = pkg.denormalize_joints(got, torch.from_numpy(max_l), torch.from_numpy(mid_p))
-    np.testing.assert_allclose(back.numpy(), gt, rtol=1e-5, atol=1e-3)
+    with np.errstate(all="ignore"):
+        for i in range(6):  # the reference's loop (joint_nor.py:15-16 == train.py:239-240)
+            want[i] = (gt[i].reshape(21, 3) - mid_p[i]) / max_l[i] + np.float32(0.5)
+    raw = want.copy()
+    want[want < 0] = 0  # train.py:241-242
+    want[want > 1] = 1
+    want[4] = 0.5
+    raw[4] = 0.5
+    assert (want == 0).any() and (want == 1).any()  # the clamp is exercised
+    for fn in (oracle.normalize_joints, onp.normalize_joints):
+        np.testing.assert_array_equal(fn(gt, max_l, mid_p).reshape(6, 21, 3), want)
+        np.testing.assert_array_equal(fn(gt, max_l, mid_p, clamp=False).reshape(6, 21, 3), raw)
+    with pytest.raises(ValueError):
+        pkg.normalize_joints(torch.from_numpy(gt), torch.from_numpy(max_l), torch.from_numpy(mid_p))
