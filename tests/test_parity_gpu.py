@@ -573,3 +573,268 @@ def test_payload_outside_the_depth_buffer_is_never_read(pkg, synth):
     out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off2).to(d), torch.from_numpy(hdr2).to(d))
     torch.cuda.synchronize()
     assert int(out.status[0]) == 2 and out.status[1:].cpu().tolist() == [0, 0, 0]
+
+
+# ---- round 2: ABI v3 -------------------------------------------------------------------------------------------
+
+def test_nan_and_inf_depths(pkg, synth):
+    """NaN depth is invalid (include/tsdf.h; kernel and oracle agree), +-inf passes |d| >= eps and makes the frame
+    degenerate (non-finite AABB): status, max_l, mid_p and the volume match the oracle in every case."""
+    rng = np.random.default_rng(17)
+    frames = []
+    h, d = synth.synth_frame(910, "crop")
+    bw, bh = h[4] - h[2], h[5] - h[3]
+    # 0: NaNs sprinkled over valid and invalid pixels (inside the spans too)
+    d0 = d.copy()
+    d0[rng.random(d0.size) < 0.05] = np.nan
+    frames.append((h, d0))
+    # 1: a whole NaN row and a whole NaN column through the blob
+    d1 = d.copy().reshape(bh, bw)
+    ys, xs = np.nonzero(d1)
+    d1[int(ys.mean()), :] = np.nan
+    d1[:, int(xs.mean())] = np.nan
+    frames.append((h, d1.reshape(-1)))
+    # 2: only NaNs and zeros -> no valid pixel -> degenerate
+    d2 = np.where(rng.random(d.size) < 0.5, np.nan, 0.0).astype(np.float32)
+    frames.append((h, d2))
+    # 3/4: one +inf / -inf pixel among valid ones -> non-finite AABB -> degenerate, zero volume, mid_p = 0
+    for v in (np.inf, -np.inf):
+        di = d.copy()
+        di[np.flatnonzero(di)[7]] = v
+        frames.append((h, di))
+    # 5: a full frame with NaNs (the 5-columns-per-lane row pass)
+    hf, df = synth.synth_frame(911, "full")
+    df = df.copy()
+    df[rng.random(df.size) < 0.02] = np.nan
+    frames.append((hf, df))
+    headers = np.stack([f[0] for f in frames])
+    offsets = np.zeros(len(frames) + 1, np.int64)
+    offsets[1:] = np.cumsum([f[1].size for f in frames])
+    depth = np.concatenate([f[1] for f in frames]).astype(np.float32)
+    for layout in ("czyx", "cxyz"):
+        got, ref, _, _ = compare(pkg, depth, offsets, headers, 32, layout)
+        assert list(got["status"]) == [0, 0, 1, 1, 1, 0]
+        assert not np.isnan(got["tsdf"]).any() and np.isfinite(got["mid_p"]).all()
+        for i in (2, 3, 4):
+            assert not got["tsdf"][i].any() and got["max_l"][i] == 0
+        np.testing.assert_array_equal(got["mid_p"][3], 0)
+    compare(pkg, depth, offsets, headers, 64, "czyx")   # no projection tables
+    # n = 6 takes the split kernel; the same frames inside a large batch take the fused one
+    big_h = np.concatenate([headers] * 100)
+    big_o = np.concatenate([[0], np.cumsum(np.tile(np.diff(offsets), 100))]).astype(np.int64)
+    big = run_hip(pkg, np.tile(depth, 100), big_o, big_h)
+    small = run_hip(pkg, depth, offsets, headers)
+    np.testing.assert_array_equal(big["tsdf"][:6], small["tsdf"])
+    np.testing.assert_array_equal(big["tsdf"][594:], small["tsdf"])
+
+
+def test_header_arithmetic_cannot_overflow(pkg, synth):
+    """right-left / bottom-top that overflow int32 mark the frame BAD_HEADER instead of wrapping around."""
+    d = dev()
+    depth, off, hdr = synth.synth_batch(3, "crop", seed0=31)
+    hdr = hdr.copy()
+    hdr[1, 2], hdr[1, 4] = -2147483648, 2147483647      # width 2^32-1 -> wraps to -1 in 32 bits
+    out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d), torch.from_numpy(hdr).to(d))
+    torch.cuda.synchronize()
+    assert out.status.cpu().tolist() == [0, 2, 0]
+    hdr[1, 2], hdr[1, 4] = 2147483647, -2147483648       # negative width whose 32-bit difference is +1
+    hdr[1, 3], hdr[1, 5] = 0, int(off[2] - off[1])
+    out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d), torch.from_numpy(hdr).to(d))
+    torch.cuda.synchronize()
+    assert out.status.cpu().tolist() == [0, 2, 0]
+
+
+@pytest.mark.parametrize("n", [5, 700])
+def test_label_normalisation_fused_and_alone(pkg, synth, n):
+    """(gt - mid_p) / max_l + 0.5, clamped to [0,1] (pre/joint_nor.py:8-18, 3D_CNN/train.py:239-242): written by
+    the voxelizer's own launch (tsdf_voxelize_labels_hip; n = 5 -> split kernel, n = 700 -> fused kernel), and by
+    the stand-alone entry; bit-exact against the oracle's restatement of the reference formula; degenerate
+    frames give 0.5; the inverse recovers the joints."""
+    d = dev()
+    rng = np.random.default_rng(n)
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=2100)
+    depth = depth.copy()
+    depth[off[2]:off[3]] = 0.0                                   # frame 2: no valid pixel
+    ref = oracle.voxelize(depth, off, hdr, R=32, n_threads=8)
+    # joints around the hand, some of them outside the cube so that the clamp bites
+    gt = (ref["mid_p"][:, None, :] + rng.normal(0, 1, (n, 21, 3)) * ref["max_l"][:, None, None] * 0.45).astype(np.float32)
+    gt = np.ascontiguousarray(gt.reshape(n, 63))
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    tg = torch.from_numpy(gt).to(d)
+    for clamp in (True, False):
+        out, nor = pkg.voxelize_labels(td, to, th, tg, clamp=clamp)
+        torch.cuda.synchronize()
+        want = oracle.normalize_joints(gt, ref["max_l"], ref["mid_p"], clamp=clamp)
+        np.testing.assert_array_equal(nor.cpu().numpy(), want)
+        np.testing.assert_array_equal(out.max_l.cpu().numpy(), ref["max_l"])
+        assert np.abs(out.tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+        alone = pkg.normalize_joints(tg, out.max_l, out.mid_p, clamp=clamp)
+        np.testing.assert_array_equal(alone.cpu().numpy(), want)
+    assert int(out.status[2]) == 1 and bool((nor[2] == 0.5).all())
+    clamped = pkg.voxelize_labels(td, to, th, tg)[1].cpu().numpy()
+    assert clamped.min() == 0.0 and clamped.max() == 1.0       # the clamp was exercised
+    # the reference formula itself, float32 numpy (joint_nor.py:15-16)
+    i = 0
+    w = (gt[i].reshape(21, 3) - ref["mid_p"][i]) / ref["max_l"][i] + np.float32(0.5)
+    np.testing.assert_array_equal(np.clip(w, 0, 1), clamped[i].reshape(21, 3))
+    # inverse (train.py:263-266) on the unclamped labels
+    raw = pkg.normalize_joints(tg, out.max_l, out.mid_p, clamp=False)
+    back = pkg.denormalize_joints(raw, out.max_l, out.mid_p).cpu().numpy()
+    ok = ref["status"] == 0
+    np.testing.assert_allclose(back[ok], gt[ok], rtol=0, atol=2e-3)
+    # [n,21,3]-shaped labels are accepted as well
+    out3, nor3 = pkg.voxelize_labels(td, to, th, tg.reshape(n, 21, 3).contiguous())
+    assert nor3.shape == (n, 21, 3) and torch.equal(nor3.reshape(n, 63), pkg.voxelize_labels(td, to, th, tg)[1])
+
+
+def test_augmented_labels(pkg, synth):
+    """tsdf_voxelize_aug_labels_hip: joints mapped with the frame's forward map (as pre/process.py:232-249 maps
+    them with the cloud's S and R), then normalised in the augmented grid — against the oracle."""
+    d = dev()
+    n = 9
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=2300)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    plain = pkg.voxelize(td, to, th)
+    mid = plain.mid_p.cpu().numpy()
+    xf, _ = pkg.augment.random_affines(mid, rng=np.random.RandomState(3))
+    gt = (mid[:, None, :] + np.random.default_rng(1).normal(0, 40, (n, 21, 3))).astype(np.float32).reshape(n, 63)
+    for R in (32, 64):
+        out, nor, gaug = pkg.voxelize_aug(td, to, th, torch.from_numpy(xf).to(d), res=R, gt=torch.from_numpy(gt).to(d))
+        torch.cuda.synchronize()
+        ref = oracle.voxelize_aug(depth, off, hdr, xf, R=R, n_threads=8)
+        want_aug = oracle.transform_joints(gt, xf)
+        np.testing.assert_array_equal(gaug.cpu().numpy(), want_aug)
+        np.testing.assert_array_equal(nor.cpu().numpy(), oracle.normalize_joints(want_aug, ref["max_l"], ref["mid_p"]))
+        np.testing.assert_allclose(want_aug, pkg.augment.apply_affine(gt, xf), rtol=0, atol=1e-3)
+        assert np.abs(out.tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_pixel_map_exact_on_goldens(pkg, golden_dir, name):
+    """SURVEY.md section 4 tier 4: the pixel every voxel gathers (pre/tsdf_numba.py:31-38), from the HIP kernel's
+    own projection tables and gather (tsdf_debug_pixmap_hip), equals the oracle's map EXACTLY on the committed
+    fixtures — explicit reference grid and the grid the kernel places itself, both layouts."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    d = dev()
+    depth = torch.from_numpy(g["depth"]).to(d)
+    off = torch.tensor([0, g["depth"].size], dtype=torch.int64, device=d)
+    hdr = torch.from_numpy(g["header"][None]).to(d)
+    grid = np.zeros((1, 8), np.float32)
+    grid[0, :3], grid[0, 3], grid[0, 4] = g["vox_ori"], g["voxel_len"], g["trunc"]
+    want_t, want_pm = oracle.voxels(g["depth"], g["header"], g["vox_ori"], g["voxel_len"], g["trunc"], want_pixmap=True)
+    assert (want_pm >= 0).any() and (want_pm == -1).any() and (want_pm < -1).any()   # all three kinds occur
+    for layout in ("czyx", "cxyz"):
+        for gr in (torch.from_numpy(grid).to(d), None):
+            t, pm, st = pkg.voxel_pixels(depth, off, hdr, layout=layout, grid=gr)
+            torch.cuda.synchronize()
+            assert int(st[0]) == 0
+            np.testing.assert_array_equal(pm[0].cpu().numpy(), want_pm)
+            tt = t[0].cpu().numpy()
+            assert np.abs((tt if layout == "czyx" else tt.transpose(0, 3, 2, 1)) - want_t).max() <= TOL
+
+
+def test_pixel_map_exact_on_a_batch(pkg, synth):
+    """The same exact comparison over seeded batches (work queue, tail help, global-gather fallback for the full
+    frames whose bounding box does not fit the LDS pool) and a resolution without projection tables."""
+    d = dev()
+    for kind, n, R in (("crop", 600, 32), ("full", 40, 32), ("crop", 12, 48)):
+        depth, off, hdr = synth.synth_batch(n, kind, seed0=5100)
+        ref = oracle.voxelize(depth, off, hdr, R=R, n_threads=8, extras=True)
+        t, pm, st = pkg.voxel_pixels(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d),
+                                     torch.from_numpy(hdr).to(d), res=R)
+        torch.cuda.synchronize()
+        pm = pm.cpu().numpy()
+        for i in range(0, n, max(1, n // 40)):
+            _, want = oracle.voxels(depth[off[i]:off[i + 1]], hdr[i], ref["ori"][i], ref["grid"][i, 4], ref["grid"][i, 5],
+                                    R=R, want_pixmap=True)
+            np.testing.assert_array_equal(pm[i], want)
+        assert np.abs(t.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 16, 64, 128])
+def test_small_batches_take_the_split_kernel(pkg, synth, n):
+    """n <= CUs/2: several workgroups per frame, each voxelizing a share of the slow axis.  Against the oracle,
+    and BIT-IDENTICAL to the same frames inside a large batch (fused kernel) — plain, both layouts, 64^3,
+    augmented, explicit grid, labels."""
+    d = dev()
+    for kind in ("full", "crop"):
+        depth, off, hdr = synth.synth_batch(n, kind, seed0=8800 + n)
+        reps = 600 // n + 1
+        bo = np.concatenate([[0], np.cumsum(np.tile(np.diff(off), reps))]).astype(np.int64)
+        bd, bh = np.tile(depth, reps), np.concatenate([hdr] * reps)
+        for R, layout in ((32, "czyx"), (32, "cxyz"), (64, "czyx"), (16, "czyx")):
+            small, ref, _, _ = compare(pkg, depth, off, hdr, R, layout)
+            if R != 64 or n <= 16:
+                big = run_hip(pkg, bd, bo, bh, R, layout)
+                np.testing.assert_array_equal(big["tsdf"][:n], small["tsdf"])
+                np.testing.assert_array_equal(big["mid_p"][:n], small["mid_p"])
+    # augmented + labels + explicit grid through the split kernel
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=8900 + n)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    ref = oracle.voxelize(depth, off, hdr, R=32, n_threads=8, extras=True)
+    xf, _ = pkg.augment.random_affines(ref["mid_p"], rng=n)
+    got = pkg.voxelize_aug(td, to, th, torch.from_numpy(xf).to(d), res=32)
+    torch.cuda.synchronize()
+    refa = oracle.voxelize_aug(depth, off, hdr, xf, R=32, n_threads=8)
+    np.testing.assert_array_equal(got.max_l.cpu().numpy(), refa["max_l"])
+    assert np.abs(got.tsdf.cpu().numpy() - refa["tsdf"]).max() <= TOL
+    grid = np.zeros((n, 8), np.float32)
+    grid[:, :3], grid[:, 3], grid[:, 4] = ref["ori"], ref["grid"][:, 4], ref["grid"][:, 5]
+    tg, st = pkg.voxelize_grid(td, to, th, torch.from_numpy(grid).to(d))
+    torch.cuda.synchronize()
+    assert np.abs(tg.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
+def test_graphs_and_eager_launches_share_nothing(pkg, synth):
+    """Work-queue ownership (include/tsdf.h): a captured launch keeps no global state, so ONE captured graph may be
+    replayed on two streams at the same time, next to eager launches on other streams, for many rounds (far more
+    launches than there are queue words) — every result bit-identical to a quiet run.  Eager launches own a word
+    per stream; releasing and re-using streams changes nothing."""
+    d = dev()
+    da, oa, ha = (torch.from_numpy(a).to(d) for a in synth.synth_batch(1100, "crop", seed0=100))   # > 2 frames/group
+    db, ob, hb = (torch.from_numpy(a).to(d) for a in synth.synth_batch(900, "crop", seed0=4000))
+    ref_a = pkg.voxelize(da, oa, ha)
+    ref_b = pkg.voxelize(db, ob, hb)
+    torch.cuda.synchronize()
+    out_g = pkg.voxelize(da, oa, ha)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream(d)
+    with torch.cuda.stream(cs):
+        with torch.cuda.graph(g, stream=cs):
+            pkg.voxelize(da, oa, ha, out=out_g)
+    s1, s2, s3, s4 = (torch.cuda.Stream(d) for _ in range(4))
+    outs_b = [pkg.voxelize(db, ob, hb) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rnd in range(40):
+        out_g.tsdf.zero_()
+        for o in outs_b:
+            o.tsdf.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            g.replay()
+        with torch.cuda.stream(s2):
+            g.replay()                      # the same graph, concurrently with itself (same outputs, same values)
+        with torch.cuda.stream(s3):
+            pkg.voxelize(db, ob, hb, out=outs_b[0])
+        with torch.cuda.stream(s4):
+            pkg.voxelize(db, ob, hb, out=outs_b[1])
+        with torch.cuda.stream(s1):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g.tsdf, ref_a.tsdf) and torch.equal(out_g.mid_p, ref_a.mid_p), rnd
+        for o in outs_b:
+            assert torch.equal(o.tsdf, ref_b.tsdf), rnd
+    # thousands of eager launches on rotating streams, never synchronised in between
+    streams = [torch.cuda.Stream(d) for _ in range(8)]
+    ring = [pkg.voxelize(db, ob, hb) for _ in streams]
+    torch.cuda.synchronize()
+    for k in range(1500):
+        si = k % len(streams)
+        with torch.cuda.stream(streams[si]):
+            pkg.voxelize(db, ob, hb, out=ring[si])
+        if k % 300 == 299:
+            pkg.release_stream(streams[si])   # forgetting a stream is harmless: it gets a word again on next use
+    torch.cuda.synchronize()
+    for o in ring:
+        assert torch.equal(o.tsdf, ref_b.tsdf)
