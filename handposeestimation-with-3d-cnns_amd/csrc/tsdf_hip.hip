@@ -1387,8 +1387,14 @@ __device__ unsigned int g_queue[kQueueSlots];
 //     tables -> voxel pass from the pool                                               VALU/store-bound
 // independently of each other, so one group's row streaming overlaps the other group's voxel arithmetic
 // and stores on the same CU.
+// (The read-only inputs are passed as separate __restrict__ parameters as well as inside KArgs: alias information
+// does not survive a by-value struct, and without it the compiler may not use scalar loads for wave-uniform
+// reads — the per-frame transform of the augmented form became 700 vector loads in the unrolled row pass.)
 template <int RT, int LAYOUT, bool AUG, bool DBG>
-__global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
+__global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const float *__restrict__ in_depth,
+                                                         const int64_t *__restrict__ in_offsets,
+                                                         const int32_t *__restrict__ in_headers,
+                                                         const double *__restrict__ in_xforms) {
   using L = Lds<RT, AUG>;
   __shared__ typename L::Block lds;
 
@@ -1447,13 +1453,13 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
       m.l = m.t = m.r = m.b = m.pad = 0;
       m.off0 = m.off1 = 0;
       if (fr < n) {
-        const int32_t *h = a.headers + 6 * (int64_t)fr;
+        const int32_t *h = in_headers + 6 * (int64_t)fr;
         m.l = h[2];
         m.t = h[3];
         m.r = h[4];
         m.b = h[5];
-        m.off0 = a.offsets[fr];
-        m.off1 = a.offsets[fr + 1];
+        m.off0 = in_offsets[fr];
+        m.off1 = in_offsets[fr + 1];
       }
       if (lane == 0) {
         ctl.hdr[group] = m;
@@ -1467,7 +1473,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
     TSDF_STAMP(kGroups * iter + group, 0);
 
     Frame f;
-    const bool hdr_ok = frame_from_header(fh, a.depth, a.depth_len, f);
+    const bool hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
     float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
     const bool want_vol = !a.aabb_only && out;
 
@@ -1481,7 +1487,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
     g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
     g.max_l = g.voxel_len = g.trunc = 0.f;
     g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
-    const double *xf = AUG ? a.xforms + 24 * (int64_t)frame : nullptr;
+    const double *xf = AUG ? in_xforms + 24 * (int64_t)frame : nullptr;
 
     bool holds_lock = false;  // group-uniform
     cap.on = false;
@@ -1692,7 +1698,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
       pm.dr = hq.pm_dr;
       auto run2 = [&](auto src) {
         if constexpr (AUG) {
-          phase2_aug<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, a.xforms + 24 * (int64_t)hq.frame, tb, src, hout,
+          phase2_aug<LAYOUT, 2 * kGW>(hq.g, cam, hq.vk, R, in_xforms + 24 * (int64_t)hq.frame, tb, src, hout,
                                       kGW + gtid, 0, R);
         } else {
           phase2<LAYOUT, 2 * kGW, DBG>(hq.g, cam, hq.vk, R, tb, hq.use_tab != 0, src, hout, kGW + gtid, 0, R, pm);
@@ -1715,7 +1721,10 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a) {
 // and voxelizes a.per slices of the slow axis.  Results are bit-identical to the fused kernel's: the
 // extents are min/max reductions (order-free) and the per-voxel code is the same.
 template <int RT, int LAYOUT, bool AUG>
-__global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a) {
+__global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const float *__restrict__ in_depth,
+                                                         const int64_t *__restrict__ in_offsets,
+                                                         const int32_t *__restrict__ in_headers,
+                                                         const double *__restrict__ in_xforms) {
   using L = Lds<RT, AUG>;
   __shared__ typename L::Block lds;
 
@@ -1729,19 +1738,19 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a) {
   if (tid == 0) ctl.cap_fail[0] = 0;
   FrameHdr fh;
   {
-    const int32_t *h = a.headers + 6 * (int64_t)frame;  // uniform: scalar loads
+    const int32_t *h = in_headers + 6 * (int64_t)frame;  // uniform: scalar loads
     fh.frame = frame;
     fh.l = h[2];
     fh.t = h[3];
     fh.r = h[4];
     fh.b = h[5];
     fh.pad = 0;
-    fh.off0 = a.offsets[frame];
-    fh.off1 = a.offsets[frame + 1];
+    fh.off0 = in_offsets[frame];
+    fh.off1 = in_offsets[frame + 1];
   }
   __syncthreads();
   Frame f;
-  const bool hdr_ok = frame_from_header(fh, a.depth, a.depth_len, f);
+  const bool hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
   float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
   const bool want_vol = !a.aabb_only && out;
 
@@ -1755,7 +1764,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a) {
   g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
   g.max_l = g.voxel_len = g.trunc = 0.f;
   g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
-  const double *xf = AUG ? a.xforms + 24 * (int64_t)frame : nullptr;
+  const double *xf = AUG ? in_xforms + 24 * (int64_t)frame : nullptr;
 
   Capture cap;
   cap.pool = (LdsF)lds.pool;
@@ -1962,7 +1971,8 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
       a.split = S;
       a.per = per;
       a.queue = nullptr;
-      hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG>), dim3(a.n * S), dim3(kWG), 0, s, a);
+      hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG>), dim3(a.n * S), dim3(kWG), 0, s, a, a.depth, a.offsets,
+                         a.headers, a.xforms);
       return hipGetLastError();
     }
   }
@@ -1971,7 +1981,8 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
   a.split = 0;
   a.per = a.R;
   a.queue = a.n > grid * kGroups ? queue_word(dev, s, false) : nullptr;  // no dynamic frames: no word needed
-  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a);
+  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
+                     a.headers, a.xforms);
   return hipGetLastError();
 }
 

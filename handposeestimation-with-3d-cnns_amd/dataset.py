@@ -2,69 +2,159 @@
 
 The reference voxelizes every frame offline (pre/read_MSRA.py:37-140, ~0.2 s per frame), writes
 ``result/<subject>/TSDF/<gesture>.npz`` and then loads *all* of it into host RAM
-(3D_CNN/dataset.py:35-38,99-117: ~76 k frames x 393 KB).  Here the dataset yields the raw frames
-(``header``, ``depth`` crop, ``gt``) straight from the ``.bin`` files and a collate function packs a
-batch, uploads it once and calls the HIP voxelizer on the training stream; what comes out is the
-tuple the reference's ``__getitem__`` returns (3D_CNN/dataset.py:73-79), batched and already on
-the GPU: ``(tsdf[n,3,R,R,R], gt[n,63], max_l[n], mid_p[n,3])``.
+(3D_CNN/dataset.py:35-38,99-117: ~76 k frames x 393 KB).  Here the dataset holds the raw frames
+(``header``, ``depth`` crop, ``gt``) — straight from the ``.bin`` files, or, after one packing pass
+(``packing.pack_tree``), from one memory-mapped ``.tsdfpk`` file per subject — and the loader packs a
+batch, uploads it once and calls the HIP voxelizer on the training stream; what comes out is the tuple
+the reference's ``__getitem__`` returns (3D_CNN/dataset.py:73-79), batched and already on the GPU:
+``(tsdf[n,3,R,R,R], gt[n,63], max_l[n], mid_p[n,3])``.
 
 Kept from the reference: directory layout ``<root>/<subject>/<gesture>/{joint.txt, 000000_depth.bin..}``
 (pre/read_MSRA.py:46-50,79,99), leave-one-subject-out split (3D_CNN/dataset.py:44-53) and the
 ``small`` subset of 4 subjects x 5 gestures (:26-31).  Fixed: ``opt`` is honoured instead of being
 ignored (:20-22).
+
+Label sign convention (the "z flip", 3D_CNN/dataset.py:107-109).  MSRA's joint.txt stores joints in the
+camera frame this pipeline uses throughout — the camera looks down -z, a point's z is MINUS its depth
+(pre/process.py:46,58; pre/tsdf_numba.py:94) — so ``mid_p`` and the labels agree as they come from the file and
+nothing is flipped here.  The reference reader negates z only for 3-D ``[n,21,3]`` label arrays, which pairs with
+writer lines that are commented out (pre/read_MSRA.py:81-82: they would have stored z pre-negated); for the
+``[n,63]`` arrays its writer really saves, the reader's branch is skipped (and ``g_t`` is then undefined — it
+crashes, App. B#11).  ``export.write_gesture(gt_3d=True)`` therefore stores z pre-negated, so that the reference
+reader's flip restores the camera-frame sign.
 """
 from __future__ import annotations
 
 import os
 import queue
 import threading
-from typing import Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, List, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 import torch.utils.data as data
 
-from . import packing
-from .voxelize import TsdfBatch, denormalize_joints, normalize_joints, voxelize  # noqa: F401
+from . import packing, shard
+from .voxelize import TsdfBatch, denormalize_joints, normalize_joints, voxelize, voxelize_labels  # noqa: F401
+
+
+def _subset(size: str) -> Tuple[int, int]:
+    if size == "full":
+        return 9, 17
+    if size == "small":
+        return 4, 5
+    raise ValueError("size must be 'full' or 'small'")
 
 
 class MSRADepthDataset(data.Dataset):
-    """Raw MSRA frames: ``__getitem__ -> (header int32[6], depth float32[N], gt float32[63])``."""
+    """Raw MSRA frames: ``__getitem__ -> (header int32[6], depth float32[N], gt float32[63])``.
+
+    root_path   the MSRA tree ``<root>/<subject>/<gesture>/...``
+    packed_dir  directory of ``<subject>.tsdfpk`` packs (``packing.pack_tree``).  Given, frames come from the
+                memory-mapped packs — one ``open()`` per subject instead of one per frame per epoch
+                (pre/read_MSRA.py:98-106 re-reads ~8,500 files per subject); missing packs are built on first use
+                when ``build_packs`` is true.
+    """
 
     def __init__(self, root_path: str, train: bool = True, test_idx: int = 2, size: str = "full",
-                 subjects: Optional[Sequence[str]] = None):
-        if size == "full":
-            n_sub, n_ges = 9, 17
-        elif size == "small":
-            n_sub, n_ges = 4, 5
-        else:
-            raise ValueError("size must be 'full' or 'small'")
+                 subjects: Optional[Sequence[str]] = None, packed_dir: Optional[str] = None,
+                 build_packs: bool = True):
+        n_sub, n_ges = _subset(size)
         self.root_path = root_path
         self.train = train
         self.test_idx = test_idx
-        all_sub = sorted(d for d in os.listdir(root_path) if os.path.isdir(os.path.join(root_path, d)))
-        all_sub = list(subjects) if subjects is not None else all_sub[:n_sub]
+        if subjects is not None:
+            all_sub = list(subjects)
+        elif root_path is not None and os.path.isdir(root_path):
+            all_sub = sorted(d for d in os.listdir(root_path) if os.path.isdir(os.path.join(root_path, d)))[:n_sub]
+        elif packed_dir is not None:
+            all_sub = sorted(f[:-7] for f in os.listdir(packed_dir) if f.endswith(".tsdfpk"))[:n_sub]
+        else:
+            raise ValueError("root_path is not a directory and no packed_dir was given")
         if not 0 <= test_idx < len(all_sub):
             raise ValueError("test_idx out of range")
         chosen = [s for i, s in enumerate(all_sub) if (i != test_idx) == train]
+        self.subjects = chosen
         self.paths: List[str] = []
+        self.packs: List[packing.PackedFrames] = []
+        self._pack_of = np.zeros(0, np.int32)     # frame -> index into self.packs
+        self._local = np.zeros(0, np.int64)       # frame -> frame index inside that pack
         gts: List[np.ndarray] = []
-        for sub in chosen:
-            sub_dir = os.path.join(root_path, sub)
-            gestures = sorted(g for g in os.listdir(sub_dir) if os.path.isdir(os.path.join(sub_dir, g)))
-            for ges in gestures[:n_ges]:
-                g_dir = os.path.join(sub_dir, ges)
-                bin_num, gt = packing.read_joint(g_dir)
-                self.paths += packing.gesture_bin_paths(g_dir, bin_num)
-                gts.append(gt)
+        if packed_dir is not None:
+            pk_of, loc = [], []
+            for sub in chosen:
+                path = os.path.join(packed_dir, sub + ".tsdfpk")
+                if not os.path.exists(path):
+                    if not build_packs:
+                        raise FileNotFoundError(path)
+                    packing.pack_tree(root_path, packed_dir, subjects=[sub])
+                pk = packing.PackedFrames.load(path, mmap=True)
+                gs = pk.group_start if pk.group_start is not None else np.array([0, len(pk)])
+                end = int(gs[min(n_ges, len(gs) - 1)])   # the first n_ges gestures (3D_CNN/dataset.py:26-31)
+                self.packs.append(pk)
+                pk_of.append(np.full(end, len(self.packs) - 1, np.int32))
+                loc.append(np.arange(end, dtype=np.int64))
+                gts.append(np.asarray(pk.gt[:end]) if pk.gt is not None else np.zeros((end, 63), np.float32))
+            if pk_of:
+                self._pack_of, self._local = np.concatenate(pk_of), np.concatenate(loc)
+        else:
+            for sub in chosen:
+                sub_dir = os.path.join(root_path, sub)
+                gestures = sorted(g for g in os.listdir(sub_dir) if os.path.isdir(os.path.join(sub_dir, g)))
+                for ges in gestures[:n_ges]:
+                    g_dir = os.path.join(sub_dir, ges)
+                    bin_num, gt = packing.read_joint(g_dir)
+                    self.paths += packing.gesture_bin_paths(g_dir, bin_num)
+                    gts.append(gt)
         self.ground_truth = np.concatenate(gts) if gts else np.zeros((0, 63), np.float32)
 
+    @property
+    def packed(self) -> bool:
+        return bool(self.packs)
+
     def __len__(self) -> int:
-        return len(self.paths)
+        return len(self._local) if self.packed else len(self.paths)
+
+    def pixels(self) -> Optional[np.ndarray]:
+        """Pixels per frame (int64[n]) when known without touching the files (packed datasets)."""
+        if not self.packed:
+            return None
+        out = np.empty(len(self), np.int64)
+        for k, pk in enumerate(self.packs):
+            m = self._pack_of == k
+            out[m] = pk.pixels[self._local[m]]
+        return out
 
     def __getitem__(self, index: int):
+        if self.packed:
+            pk = self.packs[int(self._pack_of[index])]
+            h, d = pk.frame(int(self._local[index]))
+            return np.asarray(h), np.asarray(d), self.ground_truth[index]
         header, depth = packing.read_bin(self.paths[index])
         return header, depth, self.ground_truth[index]
+
+    def take(self, idx: np.ndarray, depth_out: Optional[np.ndarray] = None) -> packing.PackedFrames:
+        """Frames ``idx`` as one packed batch (with labels).  Packed datasets gather straight from the memory
+        maps (one slice when the indices are consecutive inside a subject); otherwise the files are read."""
+        idx = np.asarray(idx, np.int64)
+        if self.packed and idx.size:
+            ks = self._pack_of[idx]
+            if (ks == ks[0]).all():
+                out = self.packs[int(ks[0])].take(self._local[idx], depth_out)
+                out.gt = self.ground_truth[idx]
+                return out
+            pk = packing.pack_frames(self.packs[int(k)].frame(int(l)) for k, l in zip(ks, self._local[idx]))
+            if depth_out is not None:
+                depth_out[: pk.depth.size] = pk.depth
+                pk.depth = depth_out[: pk.depth.size]
+            pk.gt = self.ground_truth[idx]
+            return pk
+        pk = packing.pack_frames(self[int(i)][:2] for i in idx)
+        if depth_out is not None:
+            depth_out[: pk.depth.size] = pk.depth
+            pk.depth = depth_out[: pk.depth.size]
+        pk.gt = self.ground_truth[idx] if idx.size else np.zeros((0, 63), np.float32)
+        return pk
 
 
 def collate_frames(batch) -> Tuple[packing.PackedFrames, np.ndarray]:
@@ -88,69 +178,204 @@ def voxelize_batch(pk: packing.PackedFrames, gt: np.ndarray, device, res: int = 
     return out.tsdf, tgt, out.max_l, out.mid_p, out.status
 
 
+class VoxelBatch(NamedTuple):
+    """What :class:`VoxelLoader` yields.  The first four fields are the reference's per-item tuple
+    (3D_CNN/dataset.py:73-79) batched on the GPU; ``status`` tells degenerate / malformed frames apart (the
+    reference returns None for them, tsdf_numba.py:162-171), ``gt_nor`` are the labels in the cube's [0,1] frame
+    (pre/joint_nor.py:8-18 + the clamp of 3D_CNN/train.py:241-242), written by the voxelizer's own launch."""
+
+    tsdf: torch.Tensor
+    gt: torch.Tensor
+    max_l: torch.Tensor
+    mid_p: torch.Tensor
+    status: torch.Tensor
+    gt_nor: Optional[torch.Tensor]
+
+
+def plan_batches(n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle: bool = False, seed: int = 0,
+                 epoch: int = 0, drop_last: bool = False, weights: Optional[np.ndarray] = None) -> List[np.ndarray]:
+    """The frame indices of every batch of one epoch for one rank.  Ranks own CONTIGUOUS shards of the frame range
+    (``shard.shard_bounds``, balanced by ``weights`` = pixels per frame when given) — the split BASELINE.json
+    configs[3] names; shuffling permutes inside the rank's shard.  No collective is involved."""
+    a, b = shard.shard_for_rank(n, rank, world, weights)
+    idx = np.arange(a, b, dtype=np.int64)
+    if shuffle:
+        np.random.default_rng((seed, epoch, rank)).shuffle(idx)
+    batches = [idx[i:i + batch_size] for i in range(0, idx.size, batch_size)]
+    if drop_last and batches and batches[-1].size < batch_size:
+        batches.pop()
+    return batches
+
+
+class _Staging:
+    """One reusable set of pinned host buffers + device input tensors for a batch (two of them alternate)."""
+
+    def __init__(self, max_px: int, bs: int, device, with_gt: bool):
+        self.h_depth = torch.empty(max_px, dtype=torch.float32).pin_memory()
+        self.h_off = torch.empty(bs + 1, dtype=torch.int64).pin_memory()
+        self.h_hdr = torch.empty((bs, 6), dtype=torch.int32).pin_memory()
+        self.h_gt = torch.empty((bs, 63), dtype=torch.float32).pin_memory() if with_gt else None
+        self.d_depth = torch.empty(max_px, dtype=torch.float32, device=device)
+        self.d_off = torch.empty(bs + 1, dtype=torch.int64, device=device)
+        self.d_hdr = torch.empty((bs, 6), dtype=torch.int32, device=device)
+        self.d_gt = torch.empty((bs, 63), dtype=torch.float32, device=device) if with_gt else None
+        self.copied = torch.cuda.Event()
+        self.consumed = torch.cuda.Event()
+        self.filled = threading.Event()   # host side: the worker has packed a batch into the pinned buffers
+        self.free = threading.Event()     # host side: the H2D copy out of the pinned buffers has been issued AND done
+        self.free.set()
+        self.n = 0
+        self.npx = 0
+
+
 class VoxelLoader:
     """Batches of voxel grids produced on the fly.
 
-    A worker thread reads and packs the next batches (file I/O + numpy) while the GPU voxelizes and
-    trains on the current one; uploads go through pinned buffers on a side stream, and the compute
-    stream waits on an event, so H2D copies overlap the previous batch's kernels
-    (BASELINE.json configs[2]).
+    A worker thread packs the next batch straight into one of TWO reusable pinned staging sets (no allocation
+    and no ``pin_memory()`` per batch) while the GPU voxelizes and trains on the current one; uploads run on a
+    side stream, the compute stream waits on an event, so H2D copies overlap the previous batch's kernels
+    (BASELINE.json configs[2]).  Frames shard across ranks contiguously (:func:`plan_batches`).
+    ``max_pixels`` bounds a batch's pixel count (default: ``batch_size`` full 320x240 frames).
     """
 
     def __init__(self, dataset: MSRADepthDataset, batch_size: int, device, res: int = 32,
-                 shuffle: bool = False, seed: int = 0, prefetch: int = 2, drop_last: bool = False,
-                 rank: int = 0, world: int = 1):
+                 shuffle: bool = False, seed: int = 0, drop_last: bool = False,
+                 rank: int = 0, world: int = 1, labels: bool = True, clamp: bool = True,
+                 max_pixels: Optional[int] = None, layout: str = "czyx"):
         self.ds, self.bs, self.device, self.res = dataset, int(batch_size), torch.device(device), res
-        self.shuffle, self.seed, self.prefetch, self.drop_last = shuffle, seed, max(1, prefetch), drop_last
+        self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.rank, self.world = rank, world
+        self.labels, self.clamp, self.layout = labels, clamp, layout
+        self.max_px = int(max_pixels) if max_pixels else self.bs * 320 * 240
         self.epoch = 0
+        self._sets: Optional[List[_Staging]] = None
 
-    def _indices(self) -> np.ndarray:
-        n = len(self.ds)
-        idx = np.arange(n)
-        if self.shuffle:
-            np.random.default_rng(self.seed + self.epoch).shuffle(idx)
-        return idx[self.rank::self.world]  # frames shard across ranks; no collective involved
+    def _batches(self) -> List[np.ndarray]:
+        return plan_batches(len(self.ds), self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch,
+                            self.drop_last, self.ds.pixels())
 
     def __len__(self) -> int:
-        n = len(self._indices())
-        return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
+        return len(self._batches())
 
-    def __iter__(self) -> Iterator[Tuple[torch.Tensor, ...]]:
-        idx = self._indices()
+    def __iter__(self) -> Iterator[VoxelBatch]:
+        batches = self._batches()
         self.epoch += 1
-        batches = [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
-        if self.drop_last and batches and len(batches[-1]) < self.bs:
-            batches.pop()
-        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        if self._sets is None:
+            self._sets = [_Staging(self.max_px, self.bs, self.device, True) for _ in range(2)]
+        sets = self._sets
+        for s in sets:
+            s.free.set()
+            s.filled.clear()
+        err: "queue.Queue" = queue.Queue()
+        stop = threading.Event()
 
         def work():
             try:
-                for b in batches:
-                    q.put(collate_frames([self.ds[int(i)] for i in b]))
-                q.put(None)
+                for k, b in enumerate(batches):
+                    s = sets[k & 1]
+                    while not s.free.wait(0.05):
+                        if stop.is_set():
+                            return
+                    s.free.clear()
+                    pk = self.ds.take(b, s.h_depth.numpy())
+                    if pk.depth.size > self.max_px:
+                        raise ValueError(f"batch of {pk.depth.size} pixels exceeds max_pixels={self.max_px}")
+                    s.n, s.npx = len(pk), int(pk.depth.size)
+                    s.h_off.numpy()[: s.n + 1] = pk.offsets
+                    s.h_hdr.numpy()[: s.n] = pk.headers
+                    s.h_gt.numpy()[: s.n] = pk.gt
+                    s.filled.set()
             except BaseException as e:  # surface I/O errors in the consumer
-                q.put(e)
+                err.put(e)
+                for s in sets:
+                    s.filled.set()
 
         t = threading.Thread(target=work, daemon=True)
         t.start()
         copy_stream = torch.cuda.Stream(device=self.device)
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            pk, gt = item
-            with torch.cuda.stream(copy_stream):
-                depth, offsets, headers = pk.to_torch(self.device, pin=True, non_blocking=True)
-                tgt = torch.from_numpy(np.ascontiguousarray(gt)).pin_memory().to(self.device, non_blocking=True)
-                ready = torch.cuda.Event()
-                ready.record(copy_stream)
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(ready)
-            for ten in (depth, offsets, headers, tgt):
-                ten.record_stream(cur)
-            out = voxelize(depth, offsets, headers, res=self.res)
-            yield out.tsdf, tgt, out.max_l, out.mid_p
-        t.join()
+        cur = torch.cuda.current_stream(self.device)
+        try:
+            for k in range(len(batches)):
+                s = sets[k & 1]
+                s.filled.wait()
+                if not err.empty():
+                    raise err.get()
+                s.filled.clear()
+                n, npx = s.n, s.npx
+                with torch.cuda.stream(copy_stream):
+                    if k >= 2:
+                        copy_stream.wait_event(s.consumed)   # the kernels that read this device set are done
+                    s.d_depth[:npx].copy_(s.h_depth[:npx], non_blocking=True)
+                    s.d_off[: n + 1].copy_(s.h_off[: n + 1], non_blocking=True)
+                    s.d_hdr[:n].copy_(s.h_hdr[:n], non_blocking=True)
+                    s.d_gt[:n].copy_(s.h_gt[:n], non_blocking=True)
+                    s.copied.record(copy_stream)
+                cur.wait_event(s.copied)
+                depth, off, hdr = s.d_depth[:npx], s.d_off[: n + 1], s.d_hdr[:n]
+                gt = s.d_gt[:n].clone()   # the yielded labels outlive the staging set
+                if self.labels:
+                    out, gt_nor = voxelize_labels(depth, off, hdr, gt, res=self.res, layout=self.layout, clamp=self.clamp)
+                else:
+                    out, gt_nor = voxelize(depth, off, hdr, res=self.res, layout=self.layout), None
+                s.consumed.record(cur)
+                # hand the pinned buffers back to the worker once the copy out of them has completed
+                s.copied.synchronize()
+                s.free.set()
+                yield VoxelBatch(out.tsdf, gt, out.max_l, out.mid_p, out.status, gt_nor)
+        finally:
+            stop.set()
+            t.join()
+
+
+class MSRA_Dataset(data.Dataset):
+    """The reference's dataset class with its constructor and item tuple (3D_CNN/dataset.py:16-79):
+
+        MSRA_Dataset(root_path, opt, train=True, aug=False)[i] -> (tsdf[3,32,32,32], gt[63], max_l, mid_p)
+
+    but ``root_path`` is the RAW MSRA tree (or a directory of packs, see ``packed_dir``), nothing is preprocessed
+    and nothing but the depth crops is held in host memory: items are voxelized on the GPU in blocks of
+    ``block`` consecutive frames the first time one of them is asked for, and returned as GPU tensors (the
+    reference returns numpy rows that its training loop then moves with ``.cuda()``, train.py:200,232).
+    ``opt.size`` / ``opt.test_index`` are honoured when present (the reference ignores ``opt`` and hard-codes
+    ``'small'`` / 2, :20-22); ``aug=True`` is rejected like ``DataProcess(aug=True)``: use ``voxelize_aug``.
+    For training throughput use :class:`VoxelLoader`, which overlaps reading, upload and voxelization.
+    """
+
+    def __init__(self, root_path, opt=None, train=True, aug=False, device="cuda", block: int = 1024,
+                 packed_dir: Optional[str] = None):
+        if aug:
+            raise NotImplementedError("aug=True: the reference loads '_aug' files its preprocessing cannot produce "
+                                      "(data_aug raises AxisError); use voxelize_aug for on-the-fly augmentation")
+        self.size = getattr(opt, "size", "small")
+        self.test_idx = int(getattr(opt, "test_index", 2))
+        self.PCA_SZ = int(getattr(opt, "PCA_SZ", 63))
+        self.train = train
+        self.raw = MSRADepthDataset(root_path, train=train, test_idx=self.test_idx, size=self.size,
+                                    packed_dir=packed_dir)
+        self.device = torch.device(device)
+        self.block = int(block)
+        self._cache_block = -1
+        self._cache: Optional[TsdfBatch] = None
+        self._cache_gt: Optional[torch.Tensor] = None
+
+    def __len__(self):
+        return len(self.raw)
+
+    def _load_block(self, blk: int):
+        a, b = blk * self.block, min(len(self.raw), (blk + 1) * self.block)
+        pk = self.raw.take(np.arange(a, b))
+        depth, offsets, headers = pk.to_torch(self.device, pin=False, non_blocking=False)
+        self._cache = voxelize(depth, offsets, headers, res=32)
+        self._cache_gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
+        self._cache_block = blk
+
+    def __getitem__(self, index):
+        index = int(index)
+        if not 0 <= index < len(self.raw):
+            raise IndexError(index)
+        blk = index // self.block
+        if blk != self._cache_block:
+            self._load_block(blk)
+        k = index - blk * self.block
+        c = self._cache
+        return c.tsdf[k], self._cache_gt[k], c.max_l[k], c.mid_p[k]

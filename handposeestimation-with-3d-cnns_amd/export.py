@@ -22,8 +22,10 @@ Differences from the reference writer, all deliberate and switchable:
     (pre/tsdf_for.py:118-120); pass ``layout="czyx"`` for the numba layout;
   * a ``status`` array is added to the npz (0 ok / 1 degenerate / 2 bad header): the reference crashes or
     writes garbage for such frames;
-  * ``gt_3d=True`` stores the labels as ``[n,21,3]``, the only shape the reference reader handles
-    (3D_CNN/dataset.py:107-109: ``g_t`` is undefined for the ``[n,63]`` array its own writer saves).
+  * ``gt_3d=True`` stores the labels as ``[n,21,3]`` WITH z NEGATED — the only form the reference reader handles
+    (3D_CNN/dataset.py:107-109 negates z of 3-D label arrays, pairing with the commented-out writer lines
+    pre/read_MSRA.py:81-82 that pre-negate it; for the ``[n,63]`` array its own writer saves, ``g_t`` is undefined).
+    After the reader's flip the labels are back in the camera frame (z = -depth) that ``mid_p`` lives in.
 """
 from __future__ import annotations
 
@@ -85,7 +87,8 @@ def write_gesture(sub_dir: str, gesture: str, tsdf: np.ndarray, max_l: np.ndarra
     np.savez(os.path.join(sub_dir, "TSDF", "%s.npz" % gesture), tsdf=tsdf, max_l=max_l, mid_p=mid_p, **extra)
     gt = np.asarray(ground_truth, np.float32).reshape(n, -1)
     if gt_3d:
-        gt = gt.reshape(n, 21, 3)
+        gt = gt.reshape(n, 21, 3).copy()
+        gt[:, :, 2] = -gt[:, :, 2]  # the reference reader flips it back (3D_CNN/dataset.py:107-109)
     np.save(os.path.join(sub_dir, "ground_truth", "%s.npy" % gesture), gt)
     np.save(os.path.join(sub_dir, "num", "%s.npy" % gesture), n)
     if point_cloud is not None:

@@ -10,12 +10,29 @@ and from in-memory frames.
 from __future__ import annotations
 
 import os
+import struct
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 HEADER_INTS = 6
+
+# One subject (or any set of frames) as ONE file: what pre/read_MSRA.py:98-106 re-reads from ~8,500 tiny .bin files
+# and a joint.txt per gesture, laid out as the arrays the HIP entry consumes, so that every epoch after the first is
+# a memory map instead of 76 k open() calls.  Layout (little endian, every array 64-byte aligned):
+#   0   magic "TSDFPK01"
+#   8   int64 n, int64 n_px, int64 gt_cols (0: no labels), int64 n_groups, 3 x int64 reserved
+#   64  headers int32[n,6] | offsets int64[n+1] | gt float32[n,gt_cols] | group_start int64[n_groups+1] |
+#       group names (utf-8, '\n'-joined, length-prefixed int64) | depth float32[n_px]
+# "groups" are the gestures of a subject in file order (group_start[g] .. group_start[g+1] are its frames).
+PACK_MAGIC = b"TSDFPK01"
+_ALIGN = 64
+
+
+def _pad(n: int) -> int:
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
 
 def read_bin(f_name: str) -> Tuple[np.ndarray, np.ndarray]:
@@ -65,6 +82,9 @@ class PackedFrames:
     depth: np.ndarray
     offsets: np.ndarray
     headers: np.ndarray
+    gt: Optional[np.ndarray] = None            # float32[n, 63] labels (joint.txt rows), when known
+    group_start: Optional[np.ndarray] = None   # int64[g+1]: frame ranges of the gestures, when packed from a tree
+    group_names: Optional[List[str]] = None
 
     def __len__(self) -> int:
         return int(self.headers.shape[0])
@@ -79,7 +99,89 @@ class PackedFrames:
         a, b = int(a), int(b)
         off = self.offsets[a:b + 1] - self.offsets[a]
         return PackedFrames(self.depth[self.offsets[a]:self.offsets[b]], off.astype(np.int64),
-                            self.headers[a:b])
+                            self.headers[a:b], None if self.gt is None else self.gt[a:b])
+
+    def take(self, idx: np.ndarray, depth_out: Optional[np.ndarray] = None) -> "PackedFrames":
+        """Frames ``idx`` (any order, e.g. a shuffled batch) as a packed batch.  ``depth_out`` (float32, large
+        enough) receives the depths — e.g. a pinned staging buffer — so the gather is the only copy."""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size and (np.diff(idx) == 1).all():  # contiguous: one slice, no gather
+            a, b = int(idx[0]), int(idx[-1]) + 1
+            sub = self.slice(a, b)
+            if depth_out is not None:
+                depth_out[: sub.depth.size] = sub.depth
+                sub.depth = depth_out[: sub.depth.size]
+            return sub
+        lens = self.offsets[idx + 1] - self.offsets[idx]
+        off = np.zeros(idx.size + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        total = int(off[-1])
+        out = depth_out[:total] if depth_out is not None else np.empty(total, np.float32)
+        for k, i in enumerate(idx):  # n slice copies (memcpy speed; the index arithmetic above is vectorised)
+            out[off[k]:off[k + 1]] = self.depth[self.offsets[i]:self.offsets[i + 1]]
+        return PackedFrames(out, off, self.headers[idx], None if self.gt is None else self.gt[idx])
+
+    # ---- one-file blob ----
+    def save(self, path: str) -> None:
+        """Write the pack as one ``TSDFPK01`` file (layout at the top of this module)."""
+        n = len(self)
+        headers = np.ascontiguousarray(self.headers, np.int32).reshape(n, HEADER_INTS)
+        offsets = np.ascontiguousarray(self.offsets, np.int64)
+        depth = np.ascontiguousarray(self.depth, np.float32)
+        if offsets.shape != (n + 1,) or offsets[0] != 0 or offsets[-1] != depth.size:
+            raise ValueError("offsets do not describe the depth buffer")
+        gt = None if self.gt is None else np.ascontiguousarray(self.gt, np.float32).reshape(n, -1)
+        gs = np.ascontiguousarray(self.group_start if self.group_start is not None else [0, n], np.int64)
+        names = "\n".join(self.group_names or [""] * (gs.size - 1)).encode()
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(PACK_MAGIC)
+            f.write(struct.pack("<7q", n, depth.size, 0 if gt is None else gt.shape[1], gs.size - 1, 0, 0, 0))
+            for arr in (headers, offsets, gt, gs, np.frombuffer(struct.pack("<q", len(names)) + names, np.uint8), depth):
+                f.write(b"\0" * (_pad(f.tell()) - f.tell()))
+                if arr is not None:
+                    arr.tofile(f)
+        os.replace(tmp, path)
+
+    @staticmethod
+    def load(path: str, mmap: bool = True) -> "PackedFrames":
+        """Open a ``TSDFPK01`` file.  ``mmap=True`` maps the arrays (nothing is read until used, pages are shared
+        between loader processes); ``mmap=False`` reads them into memory."""
+        with open(path, "rb") as f:
+            head = f.read(64)
+        if head[:8] != PACK_MAGIC:
+            raise ValueError(f"{path}: not a TSDFPK01 pack")
+        n, n_px, gt_cols, n_groups = struct.unpack("<4q", head[8:40])
+        size = os.path.getsize(path)
+
+        def arr(pos, dtype, shape):
+            count = int(np.prod(shape))
+            nbytes = count * np.dtype(dtype).itemsize
+            if pos + nbytes > size:
+                raise ValueError(f"{path}: truncated pack")
+            if count == 0:
+                a = np.zeros(shape, dtype)
+            elif mmap:
+                a = np.memmap(path, dtype=dtype, mode="r", offset=pos, shape=shape)
+            else:
+                a = np.fromfile(path, dtype=dtype, count=count, offset=pos).reshape(shape)
+            return a, _pad(pos + nbytes)
+
+        pos = 64
+        headers, pos = arr(pos, np.int32, (n, HEADER_INTS))
+        offsets, pos = arr(pos, np.int64, (n + 1,))
+        gt = None
+        if gt_cols:
+            gt, pos = arr(pos, np.float32, (n, gt_cols))
+        gs, pos = arr(pos, np.int64, (n_groups + 1,))
+        ln, _ = arr(pos, np.int64, (1,))
+        raw, pos2 = arr(pos + 8, np.uint8, (int(ln[0]),))
+        names = bytes(np.asarray(raw)).decode().split("\n") if n_groups else []
+        pos = _pad(pos + 8 + int(ln[0]))
+        depth, _ = arr(pos, np.float32, (n_px,))
+        if n and (int(offsets[0]) != 0 or int(offsets[-1]) != n_px):
+            raise ValueError(f"{path}: offsets do not match the depth payload")
+        return PackedFrames(depth, offsets, headers, gt, np.asarray(gs), names)
 
     def frame(self, i: int) -> Tuple[np.ndarray, np.ndarray]:
         return self.headers[i], self.depth[self.offsets[i]:self.offsets[i + 1]]
@@ -124,6 +226,82 @@ def pack_bin_files(paths: Sequence[str]) -> PackedFrames:
     """Read many ``*_depth.bin`` files into one packed batch (the reference reads and processes
     them one by one inside its frame loop, pre/read_MSRA.py:98-106)."""
     return pack_frames(read_bin(p) for p in paths)
+
+
+def _read_bin_raw(path: str) -> np.ndarray:
+    return np.fromfile(path, dtype=np.uint8)
+
+
+def pack_bin_files_fast(paths: Sequence[str], threads: int = 8) -> PackedFrames:
+    """:func:`pack_bin_files` for many files: the files are read as raw bytes by a small thread pool (file I/O
+    releases the GIL) and headers / payload sizes are validated and laid out with vectorised numpy — no per-frame
+    Python arithmetic beyond the copy into the packed buffer."""
+    n = len(paths)
+    if n == 0:
+        return pack_frames([])
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        raws = list(ex.map(_read_bin_raw, paths))
+    sizes = np.array([r.size for r in raws], np.int64)
+    if (sizes < 4 * HEADER_INTS).any():
+        raise ValueError(f"{paths[int(np.argmax(sizes < 4 * HEADER_INTS))]}: truncated header")
+    headers = np.stack([r[: 4 * HEADER_INTS].view(np.int32) for r in raws])
+    h64 = headers.astype(np.int64)
+    bw, bh = h64[:, 4] - h64[:, 2], h64[:, 5] - h64[:, 3]
+    npx = bw * bh
+    bad = (bw <= 0) | (bh <= 0) | (4 * npx != sizes - 4 * HEADER_INTS)
+    if bad.any():
+        i = int(np.argmax(bad))
+        raise ValueError(f"{paths[i]}: bbox {headers[i, 2:6].tolist()} needs {int(npx[i])} depths, "
+                         f"file holds {(int(sizes[i]) - 24) // 4}")
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum(npx, out=offsets[1:])
+    depth = np.empty(int(offsets[-1]), np.float32)
+    dview = depth.view(np.uint8)
+    for i, r in enumerate(raws):
+        dview[4 * offsets[i]:4 * offsets[i + 1]] = r[4 * HEADER_INTS:]
+    return PackedFrames(depth, offsets, np.ascontiguousarray(headers))
+
+
+def pack_subject(sub_dir: str, gestures: Optional[Sequence[str]] = None, threads: int = 8) -> PackedFrames:
+    """One MSRA subject directory ``<sub>/<gesture>/{joint.txt, 000000_depth.bin, ...}`` -> one pack with labels
+    and gesture boundaries (the per-gesture loop of pre/read_MSRA.py:78-106, minus the voxelization)."""
+    ges = list(gestures) if gestures is not None else sorted(
+        g for g in os.listdir(sub_dir) if os.path.isdir(os.path.join(sub_dir, g)))
+    packs, gts, starts = [], [], [0]
+    for g in ges:
+        g_dir = os.path.join(sub_dir, g)
+        bin_num, gt = read_joint(g_dir)
+        packs.append(pack_bin_files_fast(gesture_bin_paths(g_dir, bin_num), threads))
+        gts.append(gt)
+        starts.append(starts[-1] + bin_num)
+    if not packs:
+        pk = pack_frames([])
+        pk.gt, pk.group_start, pk.group_names = np.zeros((0, 63), np.float32), np.zeros(1, np.int64), []
+        return pk
+    offs = [np.zeros(1, np.int64)]
+    base = 0
+    for pk in packs:
+        offs.append(pk.offsets[1:] + base)
+        base += int(pk.offsets[-1])
+    return PackedFrames(np.concatenate([pk.depth for pk in packs]), np.concatenate(offs),
+                        np.concatenate([pk.headers for pk in packs]), np.concatenate(gts).astype(np.float32),
+                        np.asarray(starts, np.int64), ges)
+
+
+def pack_tree(db_dir: str, out_dir: str, subjects: Optional[Sequence[str]] = None, threads: int = 8,
+              overwrite: bool = False) -> Dict[str, str]:
+    """Pack every subject of an MSRA tree into ``<out_dir>/<subject>.tsdfpk`` (skipping packs that exist unless
+    ``overwrite``).  Returns {subject: path}.  Run once; ``dataset.MSRADepthDataset(packed_dir=...)`` then maps them."""
+    os.makedirs(out_dir, exist_ok=True)
+    subs = list(subjects) if subjects is not None else sorted(
+        d for d in os.listdir(db_dir) if os.path.isdir(os.path.join(db_dir, d)))
+    out = {}
+    for sub in subs:
+        path = os.path.join(out_dir, sub + ".tsdfpk")
+        if overwrite or not os.path.exists(path):
+            pack_subject(os.path.join(db_dir, sub), threads=threads).save(path)
+        out[sub] = path
+    return out
 
 
 def gesture_bin_paths(gesture_dir: str, bin_num: Optional[int] = None) -> List[str]:

@@ -252,3 +252,104 @@ def test_joint_normalisation_oracle_matches_reference_formula(pkg):
         np.testing.assert_array_equal(fn(gt, max_l, mid_p, clamp=False).reshape(6, 21, 3), raw)
     with pytest.raises(ValueError):
         pkg.normalize_joints(torch.from_numpy(gt), torch.from_numpy(max_l), torch.from_numpy(mid_p))
+
+
+def test_packed_subject_blob_round_trip_and_fast_reader(pkg, synth, tmp_path):
+    """a subject directory -> ONE pack file (headers, offsets, depth, gt, gesture boundaries) that
+    is memory-mapped afterwards; the threaded raw-byte reader equals the frame-by-frame read_bin path."""
+    total = _make_msra_tree(pkg, synth, tmp_path / "db", n_sub=2, n_ges=3, n_frames=4)
+    P = pkg.packing
+    g_dir = str(tmp_path / "db" / "P1" / "2")
+    slow = P.pack_bin_files(P.gesture_bin_paths(g_dir))
+    fast = P.pack_bin_files_fast(P.gesture_bin_paths(g_dir), threads=3)
+    for a, b in ((slow.depth, fast.depth), (slow.offsets, fast.offsets), (slow.headers, fast.headers)):
+        np.testing.assert_array_equal(a, b)
+    paths = P.pack_tree(str(tmp_path / "db"), str(tmp_path / "packs"))
+    assert sorted(paths) == ["P0", "P1"] and all(os.path.exists(p) for p in paths.values())
+    for mmap in (True, False):
+        pk = P.PackedFrames.load(paths["P1"], mmap=mmap)
+        assert len(pk) == 12 and pk.group_names == ["1", "2", "3"] and pk.group_start.tolist() == [0, 4, 8, 12]
+        np.testing.assert_array_equal(pk.slice(4, 8).depth, slow.depth)
+        _, gt = P.read_joint(g_dir)
+        np.testing.assert_array_equal(pk.gt[4:8], gt)
+        sub = pk.take(np.array([9, 4, 7]))
+        np.testing.assert_array_equal(sub.frame(1)[1], slow.frame(0)[1])
+        np.testing.assert_array_equal(sub.gt[2], gt[3])
+    # a damaged pack is an error, not garbage
+    bad = tmp_path / "bad.tsdfpk"
+    raw = open(paths["P0"], "rb").read()
+    open(bad, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(ValueError):
+        P.PackedFrames.load(str(bad))
+    open(bad, "wb").write(b"NOTAPACK" + raw[8:])
+    with pytest.raises(ValueError):
+        P.PackedFrames.load(str(bad))
+    with open(tmp_path / "db" / "P0" / "1" / "000001_depth.bin", "ab") as f:
+        f.write(b"\0\0\0\0")
+    with pytest.raises(ValueError):
+        P.pack_subject(str(tmp_path / "db" / "P0"))
+    assert total == 24
+
+
+def test_packed_dataset_equals_file_dataset(pkg, synth, tmp_path):
+    """MSRADepthDataset over the packs (built on first use) yields exactly the frames / labels / split of the
+    dataset over the .bin tree, and take() assembles the same batches either way."""
+    _make_msra_tree(pkg, synth, tmp_path / "db", n_sub=3, n_ges=2, n_frames=3)
+    subs = ["P0", "P1", "P2"]
+    a = pkg.MSRADepthDataset(str(tmp_path / "db"), train=True, test_idx=0, subjects=subs)
+    b = pkg.MSRADepthDataset(str(tmp_path / "db"), train=True, test_idx=0, subjects=subs,
+                             packed_dir=str(tmp_path / "packs"))
+    assert b.packed and not a.packed and len(a) == len(b) == 12
+    assert sorted(os.listdir(tmp_path / "packs")) == ["P1.tsdfpk", "P2.tsdfpk"]   # only the split's subjects
+    for i in range(len(a)):
+        for x, y in zip(a[i], b[i]):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(b.pixels(), [a[i][1].size for i in range(len(a))])
+    for idx in (np.arange(2, 6), np.array([11, 0, 7, 3]), np.arange(4, 9)):   # inside a pack, shuffled, across packs
+        pa, pb = a.take(idx), b.take(idx)
+        for f in ("depth", "offsets", "headers", "gt"):
+            np.testing.assert_array_equal(getattr(pa, f), getattr(pb, f))
+    # packs alone are enough (no raw tree on the training box), and n_ges limits by gesture boundaries
+    c = pkg.MSRADepthDataset(None, train=False, test_idx=1, subjects=subs, packed_dir=str(tmp_path / "packs"),
+                             build_packs=False)
+    assert len(c) == 6
+    with pytest.raises(FileNotFoundError):
+        pkg.MSRADepthDataset(None, train=False, test_idx=0, subjects=subs, packed_dir=str(tmp_path / "packs"),
+                             build_packs=False)
+
+
+def test_plan_batches_contiguous_rank_shards(pkg):
+    """Ranks own contiguous, pixel-balanced shards of the frame range (BASELINE configs[3]); batches cover a shard
+    exactly once; shuffling stays inside the shard and depends on (seed, epoch)."""
+    pb = pkg.dataset.plan_batches
+    w = np.random.default_rng(0).integers(8000, 26000, 1000)
+    seen = []
+    for r in range(8):
+        bs = pb(1000, 64, rank=r, world=8, weights=w)
+        flat = np.concatenate(bs)
+        assert (np.diff(flat) == 1).all()                           # contiguous
+        assert all(b.size == 64 for b in bs[:-1]) and 0 < bs[-1].size <= 64
+        seen.append(flat)
+    allf = np.concatenate(seen)
+    np.testing.assert_array_equal(allf, np.arange(1000))            # a partition, in rank order
+    loads = [w[s].sum() for s in seen]
+    assert max(loads) / (w.sum() / 8) < 1.03
+    a = np.concatenate(pb(1000, 64, rank=3, world=8, shuffle=True, seed=5, epoch=0))
+    b = np.concatenate(pb(1000, 64, rank=3, world=8, shuffle=True, seed=5, epoch=1))
+    base = np.concatenate(pb(1000, 64, rank=3, world=8))
+    assert sorted(a) == sorted(b) == sorted(base) and not np.array_equal(a, b)
+    assert len(pb(130, 64, drop_last=True)) == 2 and len(pb(130, 64)) == 3
+
+
+def test_gt_3d_export_round_trips_through_the_reference_reader(pkg, tmp_path):
+    """export.write_gesture(gt_3d=True) stores z negated; the reference reader's branch for 3-D label arrays
+    (3D_CNN/dataset.py:107-109: negate z, reshape to [n,63]) then gives back the camera-frame labels."""
+    gt = np.random.default_rng(1).normal(0, 50, (4, 63)).astype(np.float32)
+    pkg.export.write_gesture(str(tmp_path / "P0"), "1", np.zeros((4, 3, 4, 4, 4), np.float32), np.ones(4, np.float32),
+                             np.zeros((4, 3), np.float32), gt, gt_3d=True)
+    ground_truth = np.load(tmp_path / "P0" / "ground_truth" / "1.npy").astype(np.float32)
+    assert ground_truth.shape == (4, 21, 3)
+    if len(ground_truth.shape) == 3:                 # the reader's own lines, restated
+        ground_truth[:, :, 2] = -ground_truth[:, :, 2]
+        g_t = ground_truth.reshape(-1, 63)
+    np.testing.assert_array_equal(g_t, gt)

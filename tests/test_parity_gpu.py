@@ -339,6 +339,7 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
             gdir = tmp_path / f"P{s}" / f"{g + 1}"
             gdir.mkdir(parents=True)
             gt = rng.normal(0, 60, (4, 63)).astype(np.float32)
+            gts.append(gt)
             with open(gdir / "joint.txt", "w") as f:
                 f.write("4\n")
                 for row in gt:
@@ -347,23 +348,41 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
                 h, d = synth.synth_frame(2000 + len(frames), "crop")
                 pkg.packing.write_bin(str(gdir / ("%06d_depth.bin" % i)), h, d)
                 frames.append((h, d))
-    ds = pkg.MSRADepthDataset(str(tmp_path), train=True, test_idx=1, subjects=["P0", "P1"])
-    assert len(ds) == 8
-    loader = pkg.VoxelLoader(ds, batch_size=3, device=dev())
-    seen = 0
-    for tsdf, gt, max_l, mid_p in loader:
-        n = tsdf.shape[0]
-        assert tsdf.is_cuda and gt.shape == (n, 63)
-        pk = pkg.packing.pack_frames(frames[seen:seen + n])
-        ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32)
-        torch.cuda.synchronize()
-        assert np.abs(tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
-        np.testing.assert_array_equal(max_l.cpu().numpy(), ref["max_l"])
-        np.testing.assert_array_equal(mid_p.cpu().numpy(), ref["mid_p"])
-        nj = pkg.normalize_joints(gt, max_l, mid_p)
-        assert nj.shape == gt.shape and bool(torch.isfinite(nj).all())
-        seen += n
-    assert seen == 8 and len(loader) == 3
+    gts_all = np.concatenate(gts) if gts else None
+    for packed_dir in (None, str(tmp_path / "packs")):
+        ds = pkg.MSRADepthDataset(str(tmp_path), train=True, test_idx=1, subjects=["P0", "P1"], packed_dir=packed_dir)
+        assert len(ds) == 8
+        loader = pkg.VoxelLoader(ds, batch_size=3, device=dev(), max_pixels=3 * 160 * 160)
+        for epoch in range(2):                      # the staging sets are reused across batches and epochs
+            seen = 0
+            for batch in loader:
+                tsdf, gt, max_l, mid_p = batch[:4]  # the reference's tuple (3D_CNN/dataset.py:73-79)
+                n = tsdf.shape[0]
+                assert tsdf.is_cuda and gt.shape == (n, 63)
+                pk = pkg.packing.pack_frames(frames[seen:seen + n])
+                ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32)
+                torch.cuda.synchronize()
+                assert np.abs(tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+                np.testing.assert_array_equal(max_l.cpu().numpy(), ref["max_l"])
+                np.testing.assert_array_equal(mid_p.cpu().numpy(), ref["mid_p"])
+                np.testing.assert_array_equal(batch.status.cpu().numpy(), ref["status"])
+                np.testing.assert_array_equal(batch.gt_nor.cpu().numpy(),
+                                              oracle.normalize_joints(gt.cpu().numpy(), ref["max_l"], ref["mid_p"]))
+                seen += n
+            assert seen == 8 and len(loader) == 3
+    # the reference's own class name / constructor / item tuple, on the raw tree
+    class Opt:
+        size, test_index, PCA_SZ = "small", 1, 63
+    rds = pkg.MSRA_Dataset(str(tmp_path), Opt(), train=True, block=5)
+    assert len(rds) == 8
+    pk = pkg.packing.pack_frames(frames)
+    ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32)
+    for i in (0, 4, 5, 7, 2):
+        tsdf, gt, max_l, mid_p = rds[i]
+        assert tsdf.shape == (3, 32, 32, 32) and gt.shape == (63,)
+        assert np.abs(tsdf.cpu().numpy() - ref["tsdf"][i]).max() <= TOL and float(max_l) == ref["max_l"][i]
+    with pytest.raises(NotImplementedError):
+        pkg.MSRA_Dataset(str(tmp_path), Opt(), aug=True)
 
 
 def test_offline_export_on_the_gpu(pkg, synth, tmp_path):
