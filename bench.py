@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 FRAMES_PER_GPU = 1024
 RES = 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+HBM_COPY_GBS = 6290.0  # what a plain copy kernel reaches on this part (same guide, "measured copy ceiling")
 
 
 def algorithmic_bytes(offsets: np.ndarray, n: int, R: int) -> int:
@@ -88,12 +89,114 @@ def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
     }
 
 
+def _time_launches(fn, k, warm=3):
+    """Mean time of k back-to-back launches (us), HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(k):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / k * 1e3
+
+
+def extras(pkg, synth, dev, td, to, th, offsets):
+    """The other BASELINE.json configs and the small-batch latencies, measured OUTSIDE the timed region (rank 0,
+    N=1).  Every entry says what it ran; rates are device-resident unless the entry says "streamed"."""
+    ex = {}
+    # ---- small batches: launch latency as a training step sees it (reference batch size: 16, 3D_CNN/train.py:36)
+    lat = {}
+    for n in (1, 16, 64, 256):
+        d, o, h = td[: int(offsets[n])], to[: n + 1].contiguous(), th[:n].contiguous()
+        out = pkg.voxelize(d, o, h, res=RES)
+        b2b = _time_launches(lambda: pkg.voxelize(d, o, h, res=RES, out=out), 200, 20)
+        singles = []
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(40):
+            torch.cuda.synchronize()
+            a.record()
+            pkg.voxelize(d, o, h, res=RES, out=out)
+            b.record()
+            torch.cuda.synchronize()
+            singles.append(a.elapsed_time(b) * 1e3)
+        lat[str(n)] = {"back_to_back_us": round(b2b, 2), "single_launch_us_median": round(float(np.median(singles)), 2)}
+    ex["latency_full_frames"] = lat
+    # ---- other resolutions / sizes of the same fused kernel
+    def resident(name, d, o, h, R, k, offs_np, fn=None, note=""):
+        n = h.shape[0]
+        out = fn(None) if fn else pkg.voxelize(d, o, h, res=R)
+        us = _time_launches((lambda: fn(out)) if fn else (lambda: pkg.voxelize(d, o, h, res=R, out=out)), k)
+        ab = algorithmic_bytes(offs_np, n, R)
+        ex[name] = {"frames": n, "res": R, "us_per_launch": round(us, 1), "frames_per_s": round(n / us * 1e6),
+                    "algorithmic_GBps": round(ab / us / 1e3, 1), "frac_of_hbm_peak": round(ab / us / 1e3 / HBM_PEAK_GBS, 4)}
+        if note:
+            ex[name]["what"] = note
+        del out
+    resident("full_1024_r64", td, to, th, 64, 10, offsets, note="1024 full 320x240 frames -> 64^3, plain")
+    # configs[4]: 64^3 with the fused 3-D augmentation (reference distributions, augment.random_affines)
+    mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
+    xf = torch.from_numpy(pkg.augment.random_affines(mid, rng=np.random.RandomState(2026))[0]).to(dev)
+    resident("configs[4]_aug_r64", td, to, th, 64, 10, offsets,
+             fn=lambda out: pkg.voxelize_aug(td, to, th, xf, res=64, out=out),
+             note="BASELINE configs[4]: 1024 full frames -> 64^3 with the 3-D augmentation fused into the kernel")
+    # MSRA-like crops: 2,048 distinct seeded crops, repeated to the stated counts
+    crops = [synth.synth_frame(100000 + i, "crop") for i in range(2048)]
+    base = pkg.packing.pack_frames(crops)
+
+    def tiled(n):
+        reps = (n + 2047) // 2048
+        lens = np.tile(np.diff(base.offsets), reps)[:n]
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        return pkg.packing.PackedFrames(np.ascontiguousarray(np.tile(base.depth, reps)[: off[-1]]), off,
+                                        np.ascontiguousarray(np.tile(base.headers, (reps, 1))[:n]))
+
+    pk1 = tiled(1024)
+    c1 = pk1.to_torch(dev)
+    resident("crops_1024", c1[0], c1[1], c1[2], RES, 30, pk1.offsets, note="1024 MSRA-like crops (bbox side 90-160 px)")
+    del c1
+    # configs[3], one-GPU form: all nine subjects' worth of crops resident, one launch
+    pk3 = tiled(76500)
+    c3 = pk3.to_torch(dev)
+    resident("configs[3]_one_gpu", c3[0], c3[1], c3[2], RES, 3, pk3.offsets,
+             note="BASELINE configs[3] on ONE GPU: 76,500 MSRA-like crops resident, one launch (the 8-GPU form is "
+                  "bench.py --gpus 8: frames shard by rank, no collective)")
+    del c3, pk3
+    torch.cuda.empty_cache()
+    # configs[2]: one subject (8,500 crops) streamed from a pinned pack through VoxelLoader: H2D on a copy stream
+    # overlapped with the voxelizer (PCIe-inclusive: never the headline value)
+    pk2 = tiled(8500)
+    pk2.gt = np.zeros((8500, 63), np.float32)
+    ds = pkg.MSRADepthDataset.from_packs([pk2])
+    loader = pkg.VoxelLoader(ds, batch_size=1024, device=dev, max_pixels=1024 * 160 * 160)
+    rates = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nseen = 0
+        for batch in loader:
+            nseen += batch.tsdf.shape[0]
+        torch.cuda.synchronize()
+        rates.append(nseen / (time.perf_counter() - t0))
+    in_bytes = pk2.depth.size * 4
+    ex["configs[2]_streamed"] = {
+        "frames": 8500, "batch": 1024, "crops_per_s": round(max(rates[1:])),
+        "h2d_GBps": round(in_bytes * max(rates[1:]) / 8500 / 1e9, 2),
+        "what": "BASELINE configs[2]: 8,500 MSRA-like crops from a page-locked pack through dataset.VoxelLoader "
+                "(hipMemcpyAsync on a copy stream overlapped with the fused voxelizer + labels); PCIe-bound"}
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs / latency table (rank 0, N=1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,7 +310,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "tsdf_fused_kernel<32, 0, false>", "algorithmic_bytes_per_launch": abytes,
+                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command, "
+                                  "not measured in this run",
+                "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
+                "working_set_bytes": abytes,
+                "kernel": "tsdf_fused_kernel<32, 0, false, false>", "algorithmic_bytes_per_launch": abytes,
                 "launch_ms_mean": round(mean_ms, 4),
                 "single_launch_ms_median": round(float(np.median(kern_ms)), 4),
                 "single_launch_ms_min": round(float(kern_ms.min()), 4),
@@ -217,6 +324,8 @@ def main():
             line["rehearsal"] = True
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(depth, offsets, headers)
+        if world == 1 and not args.no_extras and not rehearsal:
+            line["extras"] = extras(pkg, synth, dev, td, to, th, offsets)
         print(json.dumps(line), flush=True)
 
     if dist is not None:

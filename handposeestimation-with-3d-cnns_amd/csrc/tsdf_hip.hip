@@ -340,7 +340,8 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
   // last row of the frame would that leave the buffer, so that row alone takes guarded element loads.
   auto row_pass = [&](int cbase, auto p_tag) {
     constexpr int P = decltype(p_tag)::value;
-    constexpr int kU = P <= 4 ? 4 : 3;           // rows per register buffer (bytes in flight vs VGPRs)
+    constexpr int kU = P <= 4 ? 4 : 3;           // rows per register buffer (bytes in flight vs VGPRs; deeper
+                                                 // buffers in the split kernel did not shorten its latency)
     constexpr int kStep = kWaves * kU;
     float cmin[P], cmax[P];
 #pragma unroll
@@ -985,6 +986,24 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     const int y = gi / R4;
     const double vpy = oy + (double)y * vl;
     const double ty0 = taby[3 * y], ty1 = taby[3 * y + 1], ty2 = taby[3 * y + 2];
+    // The inverse map is ((A_i0 x' + A_i1 y') + A_i2 z') + b_i with separately rounded products.  Along the lane's
+    // fixed axes the first sum does not change from slice to slice: LAYOUT 0 (x, y fixed per lane) keeps
+    // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps A_i1 y' and A_i2 z'.
+    double pre[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (LAYOUT == 0) {
+        const LdsCD tx = tabx + 3 * (f4i + j);
+        pre[j][0] = tx[0] + ty0;
+        pre[j][1] = tx[1] + ty1;
+        pre[j][2] = tx[2] + ty2;
+      } else {
+        const LdsCD tzp = tabz + 3 * (f4i + j);
+        pre[j][0] = tzp[0];
+        pre[j][1] = tzp[1];
+        pre[j][2] = tzp[2];
+      }
+    }
     for (int sl = sb + s0; sl < se; sl += sstep) {
       // ---- project the 4 voxels and gather their depths ----
       int ex[4], ry[4];
@@ -992,15 +1011,26 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
       bool ok[4];
       double vpx[4], vpz[4], az[4], tz[4], q2[4];
       bool any_near = false;
+      double sl0, sl1, sl2;  // the slice's own terms (wave-uniform)
+      if constexpr (LAYOUT == 0) {
+        const LdsCD tzp = tabz + 3 * sl;
+        sl0 = tzp[0];
+        sl1 = tzp[1];
+        sl2 = tzp[2];
+      } else {
+        const LdsCD tx = tabx + 3 * sl;
+        sl0 = tx[0] + ty0;
+        sl1 = tx[1] + ty1;
+        sl2 = tx[2] + ty2;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int x = LAYOUT == 0 ? f4i + j : sl, z = LAYOUT == 0 ? sl : f4i + j;
         vpx[j] = ox + (double)x * vl;
         vpz[j] = oz + (double)z * vl;
-        const LdsCD tx = tabx + 3 * x, tzp = tabz + 3 * z;
-        const double vx = ((tx[0] + ty0) + tzp[0]) + bi0;                        // v = T^-1(v')
-        const double vy = ((tx[1] + ty1) + tzp[1]) + bi1;
-        const double vz = ((tx[2] + ty2) + tzp[2]) + bi2;
+        const double vx = LAYOUT == 0 ? (pre[j][0] + sl0) + bi0 : (sl0 + pre[j][0]) + bi0;   // v = T^-1(v')
+        const double vy = LAYOUT == 0 ? (pre[j][1] + sl1) + bi1 : (sl1 + pre[j][1]) + bi1;
+        const double vz = LAYOUT == 0 ? (pre[j][2] + sl2) + bi2 : (sl2 + pre[j][2]) + bi2;
         const double q = -cam.focal / vz;                                        // :30
         ex[j] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                       // :31
         ry[j] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);                      // :32
@@ -1749,6 +1779,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
     fh.off1 = in_offsets[frame + 1];
   }
   __syncthreads();
+  TSDF_STAMP(0, 0);
   Frame f;
   const bool hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
   float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
@@ -1783,6 +1814,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
     ab = aabb_from_extents(fin);
     place_grid(ab, R, cam, a.grid_in, frame, g, status);
   }
+  TSDF_STAMP(0, 4);
   if (part == 0) {
     if (tid == 0) write_frame_outputs(a, frame, g, ab, status);
     write_labels(a, frame, g, status, xf, tid, kWG);
@@ -1798,6 +1830,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
   const bool use_tab = !AUG && R <= kTabR;
   fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, captured, xf, tid, kWG);
   __syncthreads();
+  TSDF_STAMP(0, 6);
   const Tabs tb = make_tabs(pg);
   const int sb = part * a.per, se = sb + a.per < R ? sb + a.per : R;
   PixMapK pm;
@@ -1816,6 +1849,9 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
   } else {
     run2((GlobalSrc)f.depth);
   }
+  TSDF_STAMP(0, 9);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSDF_STAMP(0, 11);
 }
 
 // Label normalisation on its own (pre/joint_nor.py:8-18) and its inverse (3D_CNN/train.py:263-266).

@@ -108,6 +108,18 @@ class MSRADepthDataset(data.Dataset):
                     gts.append(gt)
         self.ground_truth = np.concatenate(gts) if gts else np.zeros((0, 63), np.float32)
 
+    @classmethod
+    def from_packs(cls, packs: Sequence[packing.PackedFrames]) -> "MSRADepthDataset":
+        """A dataset over packs that are already in memory (no directory walk, no split)."""
+        self = cls.__new__(cls)
+        self.root_path, self.train, self.test_idx, self.subjects, self.paths = None, True, -1, [], []
+        self.packs = list(packs)
+        self._pack_of = np.concatenate([np.full(len(pk), k, np.int32) for k, pk in enumerate(self.packs)])
+        self._local = np.concatenate([np.arange(len(pk), dtype=np.int64) for pk in self.packs])
+        self.ground_truth = np.concatenate([np.asarray(pk.gt) if pk.gt is not None else np.zeros((len(pk), 63), np.float32)
+                                            for pk in self.packs])
+        return self
+
     @property
     def packed(self) -> bool:
         return bool(self.packs)
@@ -132,6 +144,30 @@ class MSRADepthDataset(data.Dataset):
             return np.asarray(h), np.asarray(d), self.ground_truth[index]
         header, depth = packing.read_bin(self.paths[index])
         return header, depth, self.ground_truth[index]
+
+    def pin_packs(self, limit_bytes: int = 32 << 30) -> bool:
+        """Page-lock the packs' depth payloads (if they fit ``limit_bytes``) so that contiguous batches upload
+        without a staging copy.  Returns whether the packs are pinned."""
+        if not self.packed or sum(int(pk.depth.size) * 4 for pk in self.packs) > limit_bytes:
+            return False
+        for pk in self.packs:
+            pk.pin()
+        return True
+
+    def contiguous_source(self, idx: np.ndarray):
+        """(pinned float32 tensor slice, PackedFrames view) when ``idx`` is a run of consecutive frames of one
+        pinned pack, else None."""
+        idx = np.asarray(idx, np.int64)
+        if not self.packed or idx.size == 0 or not (np.diff(idx) == 1).all():
+            return None
+        ks = self._pack_of[idx]
+        pk = self.packs[int(ks[0])]
+        if ks[0] != ks[-1] or getattr(pk, "_pinned", None) is None:
+            return None
+        a, b = int(self._local[idx[0]]), int(self._local[idx[-1]]) + 1
+        view = pk.slice(a, b)
+        view.gt = self.ground_truth[idx]
+        return pk._pinned[int(pk.offsets[a]):int(pk.offsets[b])], view
 
     def take(self, idx: np.ndarray, depth_out: Optional[np.ndarray] = None) -> packing.PackedFrames:
         """Frames ``idx`` as one packed batch (with labels).  Packed datasets gather straight from the memory
@@ -222,10 +258,12 @@ class _Staging:
         self.copied = torch.cuda.Event()
         self.consumed = torch.cuda.Event()
         self.filled = threading.Event()   # host side: the worker has packed a batch into the pinned buffers
-        self.free = threading.Event()     # host side: the H2D copy out of the pinned buffers has been issued AND done
-        self.free.set()
+        self.free = threading.Event()     # host side: the H2D copy out of the pinned buffers has been ISSUED (the
+        self.free.set()                   # worker then waits for `copied` itself, off the consumer's path)
+        self.used = False
         self.n = 0
         self.npx = 0
+        self.src = None                   # pinned tensor to upload from (the staging buffer, or a slice of a pinned pack)
 
 
 class VoxelLoader:
@@ -241,13 +279,14 @@ class VoxelLoader:
     def __init__(self, dataset: MSRADepthDataset, batch_size: int, device, res: int = 32,
                  shuffle: bool = False, seed: int = 0, drop_last: bool = False,
                  rank: int = 0, world: int = 1, labels: bool = True, clamp: bool = True,
-                 max_pixels: Optional[int] = None, layout: str = "czyx"):
+                 max_pixels: Optional[int] = None, layout: str = "czyx", pin_packs: bool = True):
         self.ds, self.bs, self.device, self.res = dataset, int(batch_size), torch.device(device), res
         self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.rank, self.world = rank, world
         self.labels, self.clamp, self.layout = labels, clamp, layout
         self.max_px = int(max_pixels) if max_pixels else self.bs * 320 * 240
         self.epoch = 0
+        self.pin_packs = pin_packs
         self._sets: Optional[List[_Staging]] = None
 
     def _batches(self) -> List[np.ndarray]:
@@ -262,10 +301,14 @@ class VoxelLoader:
         self.epoch += 1
         if self._sets is None:
             self._sets = [_Staging(self.max_px, self.bs, self.device, True) for _ in range(2)]
+            if self.pin_packs:
+                self.ds.pin_packs()
         sets = self._sets
+        torch.cuda.synchronize(self.device)
         for s in sets:
             s.free.set()
             s.filled.clear()
+            s.used = False
         err: "queue.Queue" = queue.Queue()
         stop = threading.Event()
 
@@ -277,7 +320,14 @@ class VoxelLoader:
                         if stop.is_set():
                             return
                     s.free.clear()
-                    pk = self.ds.take(b, s.h_depth.numpy())
+                    if s.used:
+                        s.copied.synchronize()   # the previous upload out of this set's pinned buffers is done
+                    direct = self.ds.contiguous_source(b)
+                    if direct is not None:            # DMA straight out of the pinned pack: no staging copy
+                        s.src, pk = direct
+                    else:
+                        pk = self.ds.take(b, s.h_depth.numpy())
+                        s.src = s.h_depth[: pk.depth.size]
                     if pk.depth.size > self.max_px:
                         raise ValueError(f"batch of {pk.depth.size} pixels exceeds max_pixels={self.max_px}")
                     s.n, s.npx = len(pk), int(pk.depth.size)
@@ -305,7 +355,7 @@ class VoxelLoader:
                 with torch.cuda.stream(copy_stream):
                     if k >= 2:
                         copy_stream.wait_event(s.consumed)   # the kernels that read this device set are done
-                    s.d_depth[:npx].copy_(s.h_depth[:npx], non_blocking=True)
+                    s.d_depth[:npx].copy_(s.src, non_blocking=True)
                     s.d_off[: n + 1].copy_(s.h_off[: n + 1], non_blocking=True)
                     s.d_hdr[:n].copy_(s.h_hdr[:n], non_blocking=True)
                     s.d_gt[:n].copy_(s.h_gt[:n], non_blocking=True)
@@ -318,9 +368,8 @@ class VoxelLoader:
                 else:
                     out, gt_nor = voxelize(depth, off, hdr, res=self.res, layout=self.layout), None
                 s.consumed.record(cur)
-                # hand the pinned buffers back to the worker once the copy out of them has completed
-                s.copied.synchronize()
-                s.free.set()
+                s.used = True
+                s.free.set()   # the copy is issued: the worker may reuse the pinned buffers once `copied` has fired
                 yield VoxelBatch(out.tsdf, gt, out.max_l, out.mid_p, out.status, gt_nor)
         finally:
             stop.set()

@@ -121,6 +121,18 @@ class PackedFrames:
             out[off[k]:off[k + 1]] = self.depth[self.offsets[i]:self.offsets[i + 1]]
         return PackedFrames(out, off, self.headers[idx], None if self.gt is None else self.gt[idx])
 
+    def pin(self) -> "PackedFrames":
+        """Move the depth payload into page-locked host memory (once): contiguous batches can then be uploaded by
+        DMA straight out of the pack, with no staging copy (``dataset.VoxelLoader``).  Needs torch with a GPU."""
+        import torch
+
+        if getattr(self, "_pinned", None) is None:
+            t = torch.empty(int(self.depth.size), dtype=torch.float32).pin_memory()
+            t.numpy()[:] = self.depth
+            self._pinned = t
+            self.depth = t.numpy()
+        return self
+
     # ---- one-file blob ----
     def save(self, path: str) -> None:
         """Write the pack as one ``TSDFPK01`` file (layout at the top of this module)."""

@@ -25,7 +25,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "tsdf_fused_kernel<32, 0, false>"
+KERNEL = "tsdf_fused_kernel<32, 0, false, false>"
 
 
 def counter_medians(d):

@@ -14,7 +14,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
-BENCH="python3 bench.py --steps 50 --warmup 5"
+BENCH="python3 bench.py --steps 50 --warmup 5 --no-extras"
 python3 bench.py --steps 50 --warmup 5 > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
 tail -1 $OUT/bench_unprofiled.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
