@@ -112,6 +112,23 @@ def collect(out, tag):
                 w.writeheader()
                 for r in rows:
                     w.writerow({k: r[k] for k in keep})
+    for sub in ("aug64/trace", "crop_trace"):
+        for f in sorted(glob.glob(os.path.join(out, sub, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
+            shutil.copy(f, os.path.join(dst, sub.split("/")[0] + "_kernel_stats.csv"))
+    for sub in ("aug64/sq_a", "aug64/sq_b", "aug64/sq_c", "crop_fetch", "crop_write"):
+        files = sorted(glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        for f in files[-1:]:
+            rows = [r for r in csv.DictReader(open(f)) if "tsdf" in r["Kernel_Name"]]
+            keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                    "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+            with open(os.path.join(dst, sub.replace("/", "_") + "_counters.csv"), "w", newline="") as g:
+                w = csv.DictWriter(g, fieldnames=keep)
+                w.writeheader()
+                for r in rows:
+                    w.writerow({k: r[k] for k in keep})
+    for f in ("ab_fill_policy.log",):
+        if os.path.exists(os.path.join(out, f)):
+            shutil.copy(os.path.join(out, f), os.path.join(dst, f))
     for f in ("summary.json", "bench_unprofiled.json"):
         if os.path.exists(os.path.join(out, f)):
             shutil.copy(os.path.join(out, f), os.path.join(dst, f))
@@ -123,8 +140,37 @@ def collect(out, tag):
     print("copied into", dst)
 
 
+def summarize2(out):
+    """Second half: the augmented-kernel and crop passes, merged into summary.json."""
+    s = json.load(open(os.path.join(out, "summary.json")))
+    try:
+        s["aug64"] = json.load(open(os.path.join(out, "aug64", "summary.json")))
+    except Exception as e:  # noqa: BLE001
+        s["aug64"] = str(e)
+    crop = {}
+    for f in glob.glob(os.path.join(out, "crop_trace", "**", "*_kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "tsdf_fused" in r["Name"]:
+                crop["kernel_trace"] = {"name": r["Name"][:80], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
+                                        "min_ns": float(r["MinNs"])}
+    for sub, cname in (("crop_fetch", "FETCH_SIZE"), ("crop_write", "WRITE_SIZE")):
+        for f in glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True):
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                 if "tsdf_fused" in r["Kernel_Name"] and r["Counter_Name"] == cname]
+            if v:
+                crop[cname + "_KiB_median"] = float(np.median(v))
+    s["crops_1024"] = crop
+    ab = os.path.join(out, "ab_fill_policy.log")
+    if os.path.exists(ab):
+        s["ab_fill_policy"] = open(ab).read().strip().splitlines()
+    json.dump(s, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    print(json.dumps({k: s[k] for k in ("crops_1024",)}, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[2] == "summarize":
         summarize(sys.argv[1])
+    elif sys.argv[2] == "summarize2":
+        summarize2(sys.argv[1])
     else:
         collect(sys.argv[1], sys.argv[3])

@@ -4,7 +4,7 @@
 set -o pipefail
 TAG=${1:-pmc_aug}; MODE=${2:-aug64}
 export TMPDIR=/tmp PMC_MODE=$MODE
-OUT=$PWD/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
+OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/exp_pmc.py > $OUT/trace.log 2>&1 || { tail -3 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/sq_a -- python3 tools/exp_pmc.py > $OUT/a.log 2>&1 || tail -3 $OUT/a.log
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/sq_b -- python3 tools/exp_pmc.py > $OUT/b.log 2>&1 || tail -3 $OUT/b.log

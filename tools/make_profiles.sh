@@ -1,16 +1,19 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): profiles of the bench command, written under gpurun_out/profiles_<tag>/.
 # Afterwards copy the summaries into profiles/<tag>/ (tracked) with tools/collect_profiles.py.
-#   tools/make_profiles.sh r01
+#   tools/make_profiles.sh r02
 # Passes (PMC counters never share a run with anything but --kernel-trace, FETCH_SIZE and WRITE_SIZE
 # need separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots):
-#   1. kernel trace + stats of `python3 bench.py`          -> per-kernel average duration
+#   1. kernel trace + stats of `python3 bench.py --no-extras` -> per-kernel average duration (headline kernel only)
 #   2. --pmc FETCH_SIZE   of the same command              -> read-side bytes (x2 for 16-B/lane streams)
 #   3. --pmc WRITE_SIZE   of the same command              -> write-side bytes (exact)
 #   4. --pmc FETCH_SIZE   of the phase-1-only entry        -> the wide-read share of pass 2
 #   5. SQ counters of the same command                     -> where the waves' cycles go
+#   6. the augmented 64^3 kernel (BASELINE configs[4]): kernel trace + three SQ passes (tools/gpu_pmc_aug.sh)
+#   7. 1024 MSRA-like crops: kernel trace + FETCH/WRITE
+#   8. paired A/B of the two TSDF_FILL policies (LDS-DMA staging vs row-span capture), if libtsdf_hip_cap.so is there
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -23,3 +26,17 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 PMC_MODE=aabb rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_aabb -- python3 tools/exp_pmc.py > $OUT/pmc_fetch_aabb.log 2>&1 || { tail -5 $OUT/pmc_fetch_aabb.log; exit 1; }
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- $BENCH --no-cpu-baseline > $OUT/pmc_sq.log 2>&1 || { tail -5 $OUT/pmc_sq.log; }
 python3 tools/collect_profiles.py $OUT summarize
+echo "--- augmented 64^3"
+tools/gpu_pmc_aug.sh profiles_$TAG/aug64 aug64 > $OUT/aug64.log 2>&1 || tail -3 $OUT/aug64.log
+echo "--- crops"
+PMC_MODE=crop rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/crop_trace -- python3 tools/exp_pmc.py > $OUT/crop_trace.log 2>&1 || tail -3 $OUT/crop_trace.log
+PMC_MODE=crop rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/crop_fetch -- python3 tools/exp_pmc.py > $OUT/crop_fetch.log 2>&1 || tail -3 $OUT/crop_fetch.log
+PMC_MODE=crop rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/crop_write -- python3 tools/exp_pmc.py > $OUT/crop_write.log 2>&1 || tail -3 $OUT/crop_write.log
+if [ -f handposeestimation-with-3d-cnns_amd/libtsdf_hip_cap.so ]; then
+  echo "--- TSDF_FILL A/B"
+  for cfg in "full 1024" "full 4096" "crop 1024" "crop 4096"; do set -- $cfg
+    PROF_KIND=$1 PROF_N=$2 AB_BLOCKS=12 python3 tools/ab_precise.py libtsdf_hip.so libtsdf_hip_cap.so 2>&1 | grep -v amdgpu.ids
+  done > $OUT/ab_fill_policy.log 2>&1
+  cat $OUT/ab_fill_policy.log
+fi
+python3 tools/collect_profiles.py $OUT summarize2
