@@ -12,22 +12,24 @@
 // Design (DESIGN.md has the numbers):
 //   * one persistent launch; one 1024-thread workgroup (16 wave64) per CU, which owns the CU's LDS.
 //     Its two 512-thread halves ("groups") each process whole frames — the first one positional, the
-//     rest from a work queue — independently of each other: one group's row streaming (memory-bound)
-//     overlaps the other group's voxel arithmetic and stores on the same CU.  Groups synchronise on LDS
-//     counters (s_barrier would span both).  The AABB and the grid placement never leave the chip;
-//   * phase 1 streams the crop ONCE with vector loads, lane <-> P consecutive columns, wave <-> rows,
+//     rest from a work queue — and take turns on the single LDS pool, so one group's row streaming
+//     (memory-bound) overlaps the other group's voxel arithmetic and stores on the same CU.  Groups
+//     synchronise on LDS counters (s_barrier would span both).  The AABB and the grid placement never
+//     leave the chip;
+//   * phase 1 streams the crop once with vector loads, lane <-> P consecutive columns, wave <-> rows,
 //     two register buffers in ping-pong behind counted vmcnt waits.  It does NOT back-project every
 //     pixel (one float64 division each): f32(f64(d)/F * (x-cx)) is monotone in d for a fixed column x
 //     (and likewise per row), so the AABB is the extreme of the formula applied to each column's /
 //     row's (min,max) valid depth — bit-identical result, 2(b_w+b_h) evaluations per wave instead of
-//     b_w*b_h; d/F uses Markstein's correction (exact quotient in 3 ops);
-//   * row-span capture: while a row is in registers, its span [first valid pixel, last valid pixel] —
-//     the only pixels of that row phase 2 can ever use; everything outside is rejected by
-//     pre/tsdf_numba.py:40 — is written to an LDS pool (one packed LDS atomic per row allocates it;
-//     the two groups allocate from opposite ends) and a per-row entry {offset, first, count} goes into
-//     the group's row table.  Depth is therefore read from HBM exactly once and the per-voxel gather is
-//     an LDS read.  A frame whose spans do not fit next to the other group's (or whose bbox is wider
-//     than 320 / taller than 256) gathers from global memory (L2) instead;
+//     b_w*b_h; d/F uses Markstein's correction (exact quotient in 3 ops).  The same pass yields the pixel
+//     rectangle that holds every valid pixel;
+//   * staging (TSDF_FILL 0, the default): that rectangle (the only pixels phase 2 can ever use —
+//     everything outside it is rejected by pre/tsdf_numba.py:36 or :40) is copied into the LDS pool by
+//     LDS-DMA (global_load_lds_dwordx4), so the per-voxel gather is an LDS read: no vector-memory
+//     latency, and stores never block loads; a rectangle larger than the pool gathers from global
+//     memory (L2).  The alternative, capturing every row's span of valid pixels into the pool while the
+//     row is in registers (TSDF_FILL 1: depth read from HBM exactly once, no lock), is implemented and
+//     parity-green but measured slower on every workload; the split kernel uses it;
 //   * phase 2: pix_x depends on (x,z) only and pix_y on (y,z) only -> both tabulated per frame in LDS
 //     (true division for q = -F/v_z, unfused multiply-add, v_cvt_i32_f64 truncation); the y table holds
 //     the row's pool entry directly.  Each lane owns 4 consecutive voxels along the layout's fastest

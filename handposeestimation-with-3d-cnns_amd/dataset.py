@@ -288,6 +288,7 @@ class VoxelLoader:
         self.epoch = 0
         self.pin_packs = pin_packs
         self._sets: Optional[List[_Staging]] = None
+        self._copy_stream = None
 
     def _batches(self) -> List[np.ndarray]:
         return plan_batches(len(self.ds), self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch,
@@ -304,8 +305,10 @@ class VoxelLoader:
             if self.pin_packs:
                 self.ds.pin_packs()
         sets = self._sets
-        torch.cuda.synchronize(self.device)
         for s in sets:
+            if s.used:
+                s.copied.synchronize()   # an abandoned previous epoch may still be uploading from this set
+                s.consumed.synchronize()
             s.free.set()
             s.filled.clear()
             s.used = False
@@ -342,7 +345,9 @@ class VoxelLoader:
 
         t = threading.Thread(target=work, daemon=True)
         t.start()
-        copy_stream = torch.cuda.Stream(device=self.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        copy_stream = self._copy_stream
         cur = torch.cuda.current_stream(self.device)
         try:
             for k in range(len(batches)):

@@ -235,7 +235,8 @@ int tsdf_denormalize_joints_hip(const float *d_pred, const float *d_max_l, const
  * extra store per voxel:  d_out_pixmap int32[n][R][R][R], indexed [z][y][x] whatever the layout, holds the
  * gathered element index (pix_y - top) * b_w + pix_x - left (pre/tsdf_numba.py:38), -1 when the voxel
  * projects outside the bounding box (:36-37), -2 - index when the pixel there is invalid (:40-41).
- * Tests compare it exactly with the oracle's map.  Slower than the production entry (smaller LDS pool).
+ * Tests compare it exactly with the oracle's map.  Slower than the production entry (the staged image is the
+ * whole bounding box instead of the rectangle of valid pixels, so more frames gather from global memory).
  */
 int tsdf_debug_pixmap_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
                           int n, int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
