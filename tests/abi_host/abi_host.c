@@ -8,7 +8,9 @@
  *
  * Frames: synthetic "hand" blobs generated here (seeded LCG), three crops of different sizes.
  * Checks: return codes, per-frame status, max_l / mid_p bit-exact, volume <= 1e-5 against the oracle, both
- * layouts, tsdf_aabb_hip, argument validation, n = 0.  Prints one line per check; exit code 0 = all passed.
+ * layouts, tsdf_aabb_hip, argument validation, n = 0; ABI v3: labels fused into the launch (tsdf_labels), the
+ * stand-alone normalisation and its inverse, the pixel-map diagnostic (exact), a launch on hipStreamPerThread,
+ * tsdf_stream_release.  Prints one line per check; exit code 0 = all passed.
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -23,6 +25,11 @@
 int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32_t *headers, int n, int R,
                          const tsdf_cam *cam, int layout, int n_threads, float *out_tsdf, float *out_max_l,
                          float *out_mid_p, int32_t *out_status, float *out_aabb, float *out_grid, float *out_ori);
+
+void tsdf_oracle_normalize_joints(const float *gt, const float *max_l, const float *mid_p, int n, int J, int clamp,
+                                  float *out);
+void tsdf_oracle_voxels(const float *depth, const int32_t *header, const float *ori, float voxel_len, float trunc_dis,
+                        int R, const tsdf_cam *cam, int layout, float *out, int32_t *pixmap);
 
 #define HIP(x)                                                                       \
   do {                                                                               \
@@ -125,6 +132,68 @@ int main(void) {
   HIP(hipMemcpyAsync(got_ab, d_ab, N * 24, hipMemcpyDeviceToHost, stream));
   HIP(hipStreamSynchronize(stream));
   check(memcmp(got_ab, ref_ab, sizeof got_ab) == 0, "  AABB bit exact");
+
+  /* ---- ABI v3 ---- */
+  {
+    enum { J = 21 };
+    static float gt[N][3 * J], ref_nor[N][3 * J], got_nor[N][3 * J], got_back[N][3 * J];
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < 3 * J; ++j) gt[i][j] = ref_m[i][j % 3] + (frand() - 0.5f) * 1.3f * ref_l[i];
+    tsdf_oracle_normalize_joints(&gt[0][0], ref_l, &ref_m[0][0], N, J, 1, &ref_nor[0][0]);
+    float *d_gt, *d_nor, *d_back;
+    HIP(hipMalloc((void **)&d_gt, sizeof gt));
+    HIP(hipMalloc((void **)&d_nor, sizeof gt));
+    HIP(hipMalloc((void **)&d_back, sizeof gt));
+    HIP(hipMemcpyAsync(d_gt, gt, sizeof gt, hipMemcpyHostToDevice, stream));
+    tsdf_labels lab = {d_gt, J, 1, d_nor, NULL};
+    check(tsdf_voxelize_labels_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s, &lab) == TSDF_OK,
+          "tsdf_voxelize_labels_hip returns TSDF_OK");
+    HIP(hipMemcpyAsync(got_nor, d_nor, sizeof gt, hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(got_l, d_l, sizeof got_l, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    check(memcmp(got_nor, ref_nor, sizeof gt) == 0, "  labels (gt - mid_p)/max_l + 0.5, clamped: bit exact");
+    check(memcmp(got_l, ref_l, sizeof got_l) == 0, "  max_l unchanged by the label path");
+    int clamped = 0;
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < 3 * J; ++j) clamped += got_nor[i][j] == 0.0f || got_nor[i][j] == 1.0f;
+    check(clamped > 0, "  the clamp was exercised");
+    check(tsdf_normalize_joints_hip(d_gt, d_l, d_m, N, J, 0, stream, d_nor) == TSDF_OK &&
+              tsdf_denormalize_joints_hip(d_nor, d_l, d_m, N, J, stream, d_back) == TSDF_OK,
+          "tsdf_normalize_joints_hip / tsdf_denormalize_joints_hip return TSDF_OK");
+    HIP(hipMemcpyAsync(got_back, d_back, sizeof gt, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    double werr = 0;
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < 3 * J; ++j) werr = fmax(werr, fabs((double)got_back[i][j] - gt[i][j]));
+    check(werr < 2e-3, "  denormalize(normalize(gt)) == gt to float32 rounding");
+    lab.n_joints = 0;
+    check(tsdf_voxelize_labels_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s, &lab) ==
+              TSDF_ERR_INVALID_ARG, "n_joints = 0 -> TSDF_ERR_INVALID_ARG");
+    /* pixel-map diagnostic against the oracle's map, frame by frame, on the oracle's own grid */
+    static float ref_grid[N][8], ref_ori[N][3];
+    tsdf_oracle_voxelize(depth, offsets, &headers[0][0], N, R, NULL, 0, 1, NULL, NULL, NULL, NULL, NULL, &ref_grid[0][0],
+                         &ref_ori[0][0]);
+    int32_t *d_pm, *got_pm = (int32_t *)malloc(sizeof(int32_t) * N * R * R * R), *ref_pm = (int32_t *)malloc(sizeof(int32_t) * R * R * R);
+    float *scratch = (float *)malloc(sizeof(float) * 3 * R * R * R);
+    HIP(hipMalloc((void **)&d_pm, sizeof(int32_t) * N * R * R * R));
+    check(tsdf_debug_pixmap_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, NULL, d_t, d_pm, d_s) == TSDF_OK,
+          "tsdf_debug_pixmap_hip returns TSDF_OK");
+    HIP(hipMemcpyAsync(got_pm, d_pm, sizeof(int32_t) * N * R * R * R, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    int pm_ok = 1;
+    for (int i = 0; i < N; ++i) {
+      tsdf_oracle_voxels(depth + offsets[i], headers[i], ref_ori[i], ref_grid[i][4], ref_grid[i][5], R, NULL, 0, scratch, ref_pm);
+      pm_ok &= memcmp(ref_pm, got_pm + (size_t)i * R * R * R, sizeof(int32_t) * R * R * R) == 0;
+    }
+    check(pm_ok, "  pixel maps equal the oracle's exactly");
+    /* the per-thread default stream is a legal stream argument too */
+    check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, hipStreamPerThread, d_t, d_l, d_m, d_s) == TSDF_OK,
+          "launch on hipStreamPerThread");
+    HIP(hipStreamSynchronize(hipStreamPerThread));
+    HIP(hipMemcpy(got_m, d_m, sizeof got_m, hipMemcpyDeviceToHost));
+    check(memcmp(got_m, ref_m, sizeof got_m) == 0, "  mid_p bit exact");
+    check(tsdf_stream_release(stream) == TSDF_OK && tsdf_stream_release(NULL) == TSDF_OK, "tsdf_stream_release");
+  }
 
   check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, 0, R, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_OK,
         "n = 0 is a no-op");

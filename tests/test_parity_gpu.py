@@ -170,7 +170,7 @@ def test_plain_c_host_program(pkg, tmp_path):
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     sys.stdout.write(r.stdout)
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("ok  ") >= 20 and "FAIL" not in r.stdout
+    assert r.stdout.count("ok  ") >= 32 and "FAIL" not in r.stdout
 
 
 def test_random_geometry_sweep(pkg):
