@@ -266,14 +266,15 @@ struct Aabb {
 constexpr int kExt = 10;
 
 
-// ---- row-span capture -------------------------------------------------------------------------
-// While phase 1 has a row in registers it copies the row's span [first valid pixel, last valid pixel]
-// into an LDS pool and records where: one 32-bit entry per bbox row,
+// ---- row-span capture (the split kernel; the fused kernel under TSDF_FILL 1) ------------------------
+// While phase 1 has a row in registers it copies the row's window of valid pixels — the lane windows from
+// the first to the last lane holding a valid pixel, cut at the row end — into an LDS pool and records
+// where: one 32-bit entry per bbox row,
 //     bits 31..18  offset in the pool, in units of 4 floats
 //     bits 17..9   bbox-relative column of the first captured pixel
 //     bits  8..0   number of captured pixels (0: the row has no valid pixel)
 // A pixel (col, row) is then  pool[4*off4 + col - first]  when  0 <= col - first < cnt, and rejected by
-// pre/tsdf_numba.py:40 otherwise (every pixel outside the span is invalid by construction).
+// pre/tsdf_numba.py:40 otherwise (every pixel outside the window is invalid by construction).
 // Every wave of the workgroup owns a fixed 1/16 of the pool and fills it with a bump pointer it keeps in a
 // scalar register: allocation costs no LDS round trip (an LDS atomic with return was tried first and cost
 // 3-7 us per frame: its latency is the LDS queue, which the other group's voxel pass keeps full).  Rows are
@@ -436,12 +437,6 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
               rmin = vmin(rmin, lo);
               rmax = vmax(rmax, hi);
             }
-#ifdef TSDF_EXP_NOREDUCE
-            // (timing experiment only: WRONG y extent) no cross-lane work per row
-            s_rmin = vmin(s_rmin, rmin);
-            s_rmax = vmax(s_rmax, rmax);
-            s_row = row;
-#else
             const float wmin = wave_min(rmin), wmax = wave_max(rmax);
             if (lane == cnt) {
               s_rmin = wmin;
@@ -449,7 +444,6 @@ __device__ __forceinline__ void phase1_extents(const Frame &f, const CamK &k, in
               s_row = row;
             }
             ++cnt;
-#endif
           }
         }
       }
