@@ -660,6 +660,12 @@ __device__ __forceinline__ float gather_px(const LdsRect src, const VoxK &k, int
   return src.p[idx];
 }
 
+// The same for a pixel given by its coordinates relative to the frame of reference (possibly outside it): the
+// on-the-fly projection of the augmented pass, which has no tables whose entries could carry the -1.
+struct Tabs;
+template <class SrcP>
+__device__ __forceinline__ float gather_rel(const SrcP src, const VoxK &k, const Tabs &tb, int relx, int rely, bool &inb);
+
 // Per-voxel value, pre/tsdf_numba.py:36-68, for the 4 voxels of one lane.  Coordinates are pre-scaled
 // by it = 1/trunc_dis:  tx = v_x*it - (pix_x-cx)*(pd*kq),  ty likewise,  tz = v_z*it + pd*it (w_z = -pd).
 //   ex[j], ry[j], ent[j]  relative pixel of voxel j (ex -1: rejected) and its row's entry
@@ -685,11 +691,23 @@ __device__ __forceinline__ unsigned voxel_values4(const int (&ex)[4], const int 
     neg[j] = pd[j] < negthr[j];                                             // w_z > v_z  :65
     any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
   }
-  // r*: |t| clamped to 1 (:58-60); stays (1,1,1) when dist > 1 (:54-57)
-  float r0[4] = {1.f, 1.f, 1.f, 1.f}, r1[4] = {1.f, 1.f, 1.f, 1.f}, r2[4] = {1.f, 1.f, 1.f, 1.f};
+  // A voxel that is rejected is 0 in all channels (:33-41), one beyond the truncation distance is (+-1,+-1,+-1)
+  // (:54-57), signed by :65-68: that is sv[j], and it is the whole answer unless the wave holds a near voxel.
+  float sv[4];
+  unsigned okm = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sv[j] = ok[j] ? (neg[j] ? -1.0f : 1.0f) : 0.0f;
+    okm |= (unsigned)ok[j] << j;
+  }
+  o0 = f4{sv[0], sv[1], sv[2], sv[3]};
+  o1 = o0;
+  o2 = o0;
   if (__any(any_near)) {
     // otherwise every voxel of this wave is rejected or beyond the truncation distance along z
     // alone: dist >= |tz| > 1 -> (1,1,1), and the x/y terms are not needed
+    float *p0 = reinterpret_cast<float *>(&o0), *p1 = reinterpret_cast<float *>(&o1),
+          *p2 = reinterpret_cast<float *>(&o2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const double a = pd64[j] * k.kq;                                      // pd/F/trunc         :43
@@ -699,26 +717,14 @@ __device__ __forceinline__ unsigned voxel_values4(const int (&ex)[4], const int 
       const double ty = __builtin_fma(dyi, a, vys);                         // (v_y - w_y)/trunc  :48, w_y = -dyi*q
       const double s = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));  // dist^2 :51-52
       const bool nearv = s <= 1.0;                                          // :54 (sqrt monotone, sqrt(1)=1)
-      const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);              // f32 store :70-72
+      // |t| clamped to 1 (:58-60), float32 (:70-72); times sv = +-1 or 0: exact, and the sign lands on a zero too
+      const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
       const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
       const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
-      r0[j] = nearv ? m0 : 1.0f;
-      r1[j] = nearv ? m1 : 1.0f;
-      r2[j] = nearv ? m2 : 1.0f;
+      p0[j] = nearv ? __fmul_rn(m0, sv[j]) : sv[j];
+      p1[j] = nearv ? __fmul_rn(m1, sv[j]) : sv[j];
+      p2[j] = nearv ? __fmul_rn(m2, sv[j]) : sv[j];
     }
-  }
-  float *p0 = reinterpret_cast<float *>(&o0), *p1 = reinterpret_cast<float *>(&o1),
-        *p2 = reinterpret_cast<float *>(&o2);
-  unsigned okm = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    // sign :65-68 and zero for rejected voxels :33-41 as bit masks
-    const unsigned sg = neg[j] ? 0x80000000u : 0u;
-    const unsigned keep = ok[j] ? 0xffffffffu : 0u;
-    p0[j] = __uint_as_float((__float_as_uint(r0[j]) | sg) & keep);
-    p1[j] = __uint_as_float((__float_as_uint(r1[j]) | sg) & keep);
-    p2[j] = __uint_as_float((__float_as_uint(r2[j]) | sg) & keep);
-    okm |= (unsigned)ok[j] << j;
   }
   return okm;
 }
@@ -814,6 +820,28 @@ __device__ __forceinline__ unsigned row_entry(const Tabs &tb, int ry) {
   } else {
     return (unsigned)ry;
   }
+}
+
+template <>
+__device__ __forceinline__ float gather_rel<GlobalSrc>(const GlobalSrc src, const VoxK &k, const Tabs &, int relx, int rely,
+                                                       bool &inb) {
+  inb = ((unsigned)relx <= (unsigned)k.dx) & ((unsigned)rely <= (unsigned)k.dy);   // :36
+  const int idx = inb ? __mul24(rely, k.stride) + relx + k.base : k.base;
+  return src[idx];                                                                  // :38-39
+}
+template <>
+__device__ __forceinline__ float gather_rel<LdsRect>(const LdsRect src, const VoxK &k, const Tabs &, int relx, int rely,
+                                                     bool &inb) {
+  inb = ((unsigned)relx <= (unsigned)k.dx) & ((unsigned)rely <= (unsigned)k.dy);
+  const int idx = inb ? __mul24(rely, k.stride) + relx + k.base : k.base;
+  return src.p[idx];
+}
+template <>
+__device__ __forceinline__ float gather_rel<LdsSrc>(const LdsSrc src, const VoxK &k, const Tabs &tb, int relx, int rely,
+                                                    bool &inb) {
+  const bool iny = (unsigned)rely <= (unsigned)k.dy;
+  const unsigned ent = iny ? tb.rowtab[iny ? rely : 0] : 0u;
+  return gather_px(src, k, relx, rely, ent, inb);   // a column outside the row's window (or the box) fails its test
 }
 
 // The voxel pass over slow-axis slices [sb, se).  T threads take part (tid in [0, T)): T = kGW when a group
@@ -1028,21 +1056,19 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         const double vy = LAYOUT == 0 ? (pre[j][1] + sl1) + bi1 : (sl1 + pre[j][1]) + bi1;
         const double vz = LAYOUT == 0 ? (pre[j][2] + sl2) + bi2 : (sl2 + pre[j][2]) + bi2;
         const double q = -cam.focal / vz;                                        // :30
-        ex[j] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                       // :31
-        ry[j] = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);                      // :32
+        ex[j] = trunc_i32(mul_then_add(vx, q, cam.cx)) - vk.px0;                 // :31, relative; may lie outside
+        ry[j] = trunc_i32(mul_then_add(-vy, q, cam.cy)) - vk.py0;                // :32
         bool inb;
-        pd[j] = gather_px(src, vk, ex[j], ry[j], row_entry<SrcP>(tb, ry[j]), inb);  // :36-39
+        pd[j] = gather_rel<SrcP>(src, vk, tb, ex[j], ry[j], inb);                // :36-39
         ok[j] = inb & (__builtin_fabsf(pd[j]) >= vk.eps);                        // :40
       }
       // ---- z component first: a wave whose voxels are all beyond the truncation distance along z' alone
       // needs nothing else (dist >= |tz| > 1 -> (1,1,1)); one whose voxels are all rejected needs nothing ----
       double wx[4], wy[4];
-      float o0[4], o1[4], o2[4];
+      float sv[4];  // 0 for a rejected voxel, else the sign of :65-68 as +-1: the whole answer unless near
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o0[j] = o1[j] = o2[j] = 1.0f;
-        az[j] = vpz[j];
-      }
+      for (int j = 0; j < 4; ++j) sv[j] = 0.0f;
+      f4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
       if (__any(ok[0] | ok[1] | ok[2] | ok[3])) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1052,8 +1078,14 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
           az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
           tz[j] = (vpz[j] - az[j]) * vk.it;                                        // :49
           any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
+          sv[j] = ok[j] ? (az[j] > vpz[j] ? -1.0f : 1.0f) : 0.0f;                  // w'_z > v'_z  :65
         }
+        o0 = f4{sv[0], sv[1], sv[2], sv[3]};
+        o1 = o0;
+        o2 = o0;
         if (__any(any_near)) {
+          float *p0 = reinterpret_cast<float *>(&o0), *p1 = reinterpret_cast<float *>(&o1),
+                *p2 = reinterpret_cast<float *>(&o2);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const double wz = -(double)pd[j];
@@ -1065,24 +1097,16 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
             const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
             const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
             const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
-            o0[j] = nearv ? m0 : 1.0f;
-            o1[j] = nearv ? m1 : 1.0f;
-            o2[j] = nearv ? m2 : 1.0f;
+            p0[j] = nearv ? __fmul_rn(m0, sv[j]) : sv[j];                          // exact: sv is +-1 or 0
+            p1[j] = nearv ? __fmul_rn(m1, sv[j]) : sv[j];
+            p2[j] = nearv ? __fmul_rn(m2, sv[j]) : sv[j];
           }
         }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned keep = ok[j] ? 0xffffffffu : 0u;
-        const unsigned sg = (az[j] > vpz[j] ? 0x80000000u : 0u) & keep;         // w'_z > v'_z  :65
-        o0[j] = __uint_as_float((__float_as_uint(o0[j]) & keep) | sg);
-        o1[j] = __uint_as_float((__float_as_uint(o1[j]) & keep) | sg);
-        o2[j] = __uint_as_float((__float_as_uint(o2[j]) & keep) | sg);
-      }
       const int64_t e = ((int64_t)sl * R + y) * R + f4i;  // o[c][slow][y][fast]
-      store_vol4(out + e, f4{o0[0], o0[1], o0[2], o0[3]});
-      store_vol4(out + R3 + e, f4{o1[0], o1[1], o1[2], o1[3]});
-      store_vol4(out + 2 * R3 + e, f4{o2[0], o2[1], o2[2], o2[3]});
+      store_vol4(out + e, o0);
+      store_vol4(out + R3 + e, o1);
+      store_vol4(out + 2 * R3 + e, o2);
     }
   }
 }
