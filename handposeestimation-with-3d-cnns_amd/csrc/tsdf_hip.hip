@@ -125,6 +125,12 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// min(|a|, b): the absolute value is a source modifier, not an instruction
+__device__ __forceinline__ float vminabs(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // ---- wave64 reductions: one DPP VALU op per step (s_nop 1 covers the VALU-write -> DPP-read hazard;
 // lanes whose DPP source is out of range are write-disabled and keep their value) ----------------
 #define TSDF_DPP_REDUCE(OP)                                                             \
@@ -595,9 +601,20 @@ struct VoxK {
   // global memory (everything outside that rectangle is rejected by pre/tsdf_numba.py:36 or :40).
   int px0, py0;  // image coordinates of that frame's first pixel
   int dx, dy;    // its extent - 1 (inclusive upper bounds of relative coordinates)
-  int stride;    // global gather: elements per row of the crop ...
-  int base;      // ... and index of the frame of reference's first pixel in it
+  int stride;    // rows of the gather source: elements per row (the crop's, or the staged rectangle's) ...
+  int stride4;   // ... and bytes per row
+  int base;      // global gather: index of the frame of reference's first pixel in the crop (the source pointer
+                 // handed to the voxel pass already points there)
+  double dxc, dyc;  // px0 - cx, py0 - cy: pix - c = relative coordinate + this
 };
+
+// Column codes.  The x table (and the on-the-fly projection) hand the voxel pass a column as its BYTE offset in
+// the row, 4 * column, or kColBad when the voxel projects outside the frame of reference; a row is its index or
+// -1.  With that, row * stride4 + code is the gather's byte offset, and it is negative exactly when the pixel
+// does not exist (row -1: code - stride4 < 0; kColBad swamps any row) — one compare and one max instead of an
+// or, a compare, a select and a shift per voxel.
+constexpr int kColBad = -(1 << 30);
+__device__ __forceinline__ int col_code(int rel) { return rel >= 0 ? rel << 2 : kColBad; }
 
 __device__ __forceinline__ void zero_volume(float *__restrict__ out, int R, int tid, int T, int part, int parts) {
   const int n4 = 3 * R * R * R / 4;
@@ -639,25 +656,25 @@ struct LdsRect {
   LdsSrc p;
 };
 
-// Depth of pixel (ex, row): pre/tsdf_numba.py:36-39.  `ent` is the row's pool entry (LDS) or its
-// rectangle-relative index (global); inb = the pixel exists in the source.  The load is always in bounds.
-__device__ __forceinline__ float gather_px(const LdsSrc pool, const VoxK &, int ex, int, unsigned ent, bool &inb) {
-  const int rel = ex - (int)((ent >> 9) & 511u);
+// Depth of pixel (column code xc, row): pre/tsdf_numba.py:36-39.  `ent` is the row's pool entry (span capture);
+// inb = the pixel exists in the source.  The load is always in bounds.
+__device__ __forceinline__ float gather_px(const LdsSrc pool, const VoxK &, int xc, int, unsigned ent, bool &inb) {
+  const int rel = (xc >> 2) - (int)((ent >> 9) & 511u);
   inb = (unsigned)rel < (ent & 511u);
   const int idx = inb ? (int)((ent >> 18) << 2) + rel : 0;
   return pool[idx];
 }
-__device__ __forceinline__ float gather_px(const GlobalSrc src, const VoxK &k, int ex, int ry, unsigned, bool &inb) {
-  inb = (ex | ry) >= 0;
-  int idx = __mul24(ry, k.stride) + ex + k.base;
-  idx = inb ? idx : k.base;
-  return src[idx];
+__device__ __forceinline__ float gather_px(const GlobalSrc src, const VoxK &k, int xc, int ry, unsigned, bool &inb) {
+  int off = __mul24(ry, k.stride4) + xc;   // bytes; negative iff the pixel is outside (see kColBad)
+  inb = off >= 0;
+  off = off > 0 ? off : 0;                  // the load is always in bounds
+  return *(GlobalSrc)((const __attribute__((address_space(1))) char *)src + off);
 }
-__device__ __forceinline__ float gather_px(const LdsRect src, const VoxK &k, int ex, int ry, unsigned, bool &inb) {
-  inb = (ex | ry) >= 0;
-  int idx = __mul24(ry, k.stride) + ex + k.base;
-  idx = inb ? idx : k.base;
-  return src.p[idx];
+__device__ __forceinline__ float gather_px(const LdsRect src, const VoxK &k, int xc, int ry, unsigned, bool &inb) {
+  int off = __mul24(ry, k.stride4) + xc;
+  inb = off >= 0;
+  off = off > 0 ? off : 0;
+  return *(LdsSrc)((const __attribute__((address_space(3))) char *)src.p + off);
 }
 
 // The same for a pixel given by its coordinates relative to the frame of reference (possibly outside it): the
@@ -668,7 +685,7 @@ __device__ __forceinline__ float gather_rel(const SrcP src, const VoxK &k, const
 
 // Per-voxel value, pre/tsdf_numba.py:36-68, for the 4 voxels of one lane.  Coordinates are pre-scaled
 // by it = 1/trunc_dis:  tx = v_x*it - (pix_x-cx)*(pd*kq),  ty likewise,  tz = v_z*it + pd*it (w_z = -pd).
-//   ex[j], ry[j], ent[j]  relative pixel of voxel j (ex -1: rejected) and its row's entry
+//   ex[j], ry[j], ent[j]  relative pixel of voxel j (ex: column CODE, see kColBad; ry -1: rejected) and its row's entry
 //   vxs[j], vys, vzs[j]   pre-scaled voxel centre;   negthr[j] = f32_round_up(-v_z)
 // Returns the mask of voxels that passed :36 and :40 (bit j).
 template <class SrcP>
@@ -711,16 +728,16 @@ __device__ __forceinline__ unsigned voxel_values4(const int (&ex)[4], const int 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const double a = pd64[j] * k.kq;                                      // pd/F/trunc         :43
-      const double dxi = (double)(ex[j] + k.px0) + k.ncx;                   // pix_x - cx         :44
-      const double dyi = (double)(ry[j] + k.py0) - k.cy;                    // pix_y - cy         :45
+      const double dxi = __builtin_fma((double)ex[j], 0.25, k.dxc);         // pix_x - cx         :44 (exact)
+      const double dyi = (double)ry[j] + k.dyc;                             // pix_y - cy         :45
       const double tx = __builtin_fma(-dxi, a, vxs[j]);                     // (v_x - w_x)/trunc  :47
       const double ty = __builtin_fma(dyi, a, vys);                         // (v_y - w_y)/trunc  :48, w_y = -dyi*q
       const double s = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));  // dist^2 :51-52
       const bool nearv = s <= 1.0;                                          // :54 (sqrt monotone, sqrt(1)=1)
       // |t| clamped to 1 (:58-60), float32 (:70-72); times sv = +-1 or 0: exact, and the sign lands on a zero too
-      const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
-      const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
-      const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
+      const float m0 = vminabs((float)tx, 1.0f);
+      const float m1 = vminabs((float)ty, 1.0f);
+      const float m2 = vminabs((float)tz[j], 1.0f);
       p0[j] = nearv ? __fmul_rn(m0, sv[j]) : sv[j];
       p1[j] = nearv ? __fmul_rn(m1, sv[j]) : sv[j];
       p2[j] = nearv ? __fmul_rn(m2, sv[j]) : sv[j];
@@ -761,7 +778,7 @@ __device__ __forceinline__ int pixmap_value(const PixMapK &pm, int ex, int ry, b
 // LDS-resident per-frame tables, one set per group.  The pixel a voxel projects to factorises: pix_x
 // depends on (x, z) only and pix_y on (y, z) only, so for R <= kTabR both are tabulated once per frame
 // (R*R entries each, one pair per thread) instead of 3 float64 operations + a range test per voxel.
-//   pxtab[.]  relative pix_x, or -1
+//   pxtab[.]  column code of the relative pix_x (4 * column, or kColBad)
 //   pytab[.]  LDS gather: the pool entry of row pix_y (0: outside the bounding box)
 //             global gather: relative pix_y, or -1
 //   pyrow[.]  LDS gather: relative pix_y (0 when outside)              (uint8; rows < kMaxRows)
@@ -826,14 +843,14 @@ template <>
 __device__ __forceinline__ float gather_rel<GlobalSrc>(const GlobalSrc src, const VoxK &k, const Tabs &, int relx, int rely,
                                                        bool &inb) {
   inb = ((unsigned)relx <= (unsigned)k.dx) & ((unsigned)rely <= (unsigned)k.dy);   // :36
-  const int idx = inb ? __mul24(rely, k.stride) + relx + k.base : k.base;
+  const int idx = inb ? __mul24(rely, k.stride) + relx : 0;
   return src[idx];                                                                  // :38-39
 }
 template <>
 __device__ __forceinline__ float gather_rel<LdsRect>(const LdsRect src, const VoxK &k, const Tabs &, int relx, int rely,
                                                      bool &inb) {
   inb = ((unsigned)relx <= (unsigned)k.dx) & ((unsigned)rely <= (unsigned)k.dy);
-  const int idx = inb ? __mul24(rely, k.stride) + relx + k.base : k.base;
+  const int idx = inb ? __mul24(rely, k.stride) + relx : 0;
   return src.p[idx];
 }
 template <>
@@ -841,7 +858,7 @@ __device__ __forceinline__ float gather_rel<LdsSrc>(const LdsSrc src, const VoxK
                                                     bool &inb) {
   const bool iny = (unsigned)rely <= (unsigned)k.dy;
   const unsigned ent = iny ? tb.rowtab[iny ? rely : 0] : 0u;
-  return gather_px(src, k, relx, rely, ent, inb);   // a column outside the row's window (or the box) fails its test
+  return gather_px(src, k, relx << 2, rely, ent, inb);   // a column outside the row's window (or the box) fails its test
 }
 
 // The voxel pass over slow-axis slices [sb, se).  T threads take part (tid in [0, T)): T = kGW when a group
@@ -894,7 +911,7 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
           ry[0] = IsLds<SrcP>::value ? (int)tb.pyrow[z * R + y] : (int)ent[0];
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ex[j] = project_rel(vx[j], ze.q, cam.cx, vk.px0, vk.dx);  // :31
+          for (int j = 0; j < 4; ++j) ex[j] = col_code(project_rel(vx[j], ze.q, cam.cx, vk.px0, vk.dx));  // :31
           ry[0] = project_rel(-vy, ze.q, cam.cy, vk.py0, vk.dy);                                 // :32
           ent[0] = row_entry<SrcP>(tb, ry[0]);
         }
@@ -911,7 +928,7 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
         if constexpr (DBG) {
           const bool rin = IsLds<SrcP>::value ? ent[0] != 0u : ry[0] >= 0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pm.out[e + j] = pixmap_value(pm, ex[j], ry[0], rin, (okm >> j) & 1u);
+          for (int j = 0; j < 4; ++j) pm.out[e + j] = pixmap_value(pm, ex[j] >> 2, ry[0], rin, (okm >> j) & 1u);
         }
       }
     } else {
@@ -954,7 +971,7 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
           ex[0] = e.x; ex[1] = e.y; ex[2] = e.z; ex[3] = e.w;
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ex[j] = project_rel(vx, q[j], cam.cx, vk.px0, vk.dx);
+          for (int j = 0; j < 4; ++j) ex[j] = col_code(project_rel(vx, q[j], cam.cx, vk.px0, vk.dx));
         }
         f4 o0, o1, o2;
         const unsigned okm = voxel_values4(ex, ry, ent, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
@@ -966,7 +983,7 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const bool rin = IsLds<SrcP>::value ? ent[j] != 0u : ry[j] >= 0;
-            pm.out[((int64_t)(f4i + j) * R + y) * R + x] = pixmap_value(pm, ex[j], ry[j], rin, (okm >> j) & 1u);
+            pm.out[((int64_t)(f4i + j) * R + y) * R + x] = pixmap_value(pm, ex[j] >> 2, ry[j], rin, (okm >> j) & 1u);
           }
         }
       }
@@ -1073,8 +1090,8 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           q2[j] = div_by_focal((double)pd[j], cam);                                // :43
-          wx[j] = ((double)(ex[j] + vk.px0) - cam.cx) * q2[j];                     // :44
-          wy[j] = -((double)(ry[j] + vk.py0) - cam.cy) * q2[j];                    // :45
+          wx[j] = ((double)ex[j] + vk.dxc) * q2[j];                                // :44 (pix_x - cx, exact)
+          wy[j] = -((double)ry[j] + vk.dyc) * q2[j];                               // :45
           az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
           tz[j] = (vpz[j] - az[j]) * vk.it;                                        // :49
           any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
@@ -1094,9 +1111,9 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
             const double tx = (vpx[j] - ax) * vk.it, ty = (vpy - ay) * vk.it;      // :47-48
             const double s2 = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));
             const bool nearv = s2 <= 1.0;                                          // :54
-            const float m0 = vmin(__builtin_fabsf((float)tx), 1.0f);
-            const float m1 = vmin(__builtin_fabsf((float)ty), 1.0f);
-            const float m2 = vmin(__builtin_fabsf((float)tz[j]), 1.0f);
+            const float m0 = vminabs((float)tx, 1.0f);
+            const float m1 = vminabs((float)ty, 1.0f);
+            const float m2 = vminabs((float)tz[j], 1.0f);
             p0[j] = nearv ? __fmul_rn(m0, sv[j]) : sv[j];                          // exact: sv is +-1 or 0
             p1[j] = nearv ? __fmul_rn(m1, sv[j]) : sv[j];
             p2[j] = nearv ? __fmul_rn(m2, sv[j]) : sv[j];
@@ -1375,7 +1392,10 @@ __device__ __forceinline__ VoxK make_voxk(const CamK &cam, const Grid &g, const 
   vk.dx = w - 1;
   vk.dy = h - 1;
   vk.stride = mode == kFillRect ? rect_stride : f.bw;
+  vk.stride4 = 4 * vk.stride;
   vk.base = mode == kFillGlobal ? r0 * f.bw + c0 : 0;
+  vk.dxc = (double)vk.px0 - cam.cx;
+  vk.dyc = (double)vk.py0 - cam.cy;
   return vk;
 }
 
@@ -1409,7 +1429,7 @@ __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &c
       const double q = -cam.focal / (oz + (double)z * vl);                              // :30
       const double vx = ox + (double)i * vl, vy = oy + (double)i * vl;                  // :26-27
       const int ti = tab_index<LAYOUT>(i, z, R);
-      pg.pxtab[ti] = project_rel(vx, q, cam.cx, vk.px0, vk.dx);                         // :31
+      pg.pxtab[ti] = col_code(project_rel(vx, q, cam.cx, vk.px0, vk.dx));               // :31
       const int ry = project_rel(-vy, q, cam.cy, vk.py0, vk.dy);                        // :32
       if (spans) {
         pg.pytab[ti] = ry >= 0 ? pg.rowtab[ry] : 0u;
@@ -1665,7 +1685,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
               HelpReq hq;
               hq.g = g;
               hq.vk = vk;
-              hq.src = f.depth;
+              hq.src = f.depth + vk.base;
               hq.mode = mode;
               hq.owner = group;
               hq.out = out;
@@ -1707,7 +1727,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         } else if (mode == kFillSpans) {
           run2((LdsSrc)lds.pool);
         } else {
-          run2((GlobalSrc)f.depth);
+          run2((GlobalSrc)(f.depth + vk.base));
         }
       }
     }
@@ -1867,7 +1887,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
   if (captured) {
     run2((LdsSrc)lds.pool);
   } else {
-    run2((GlobalSrc)f.depth);
+    run2((GlobalSrc)(f.depth + vk.base));
   }
   TSDF_STAMP(0, 9);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
