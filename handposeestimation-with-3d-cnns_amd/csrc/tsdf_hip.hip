@@ -1149,6 +1149,8 @@ struct KArgs {
   int n_joints, clamp;
   int32_t *pixmap;        // diagnostic pixel map (DBG instantiations only)
   int split, per;         // split kernel: workgroups per frame, slow-axis slices per workgroup
+  float *xchg;            // split kernel: this stream's mailboxes for partial extents, or null (see the kernel)
+  unsigned int seq;       // ... and the number this launch tags them with
 };
 
 // ---- synchronisation inside one half-workgroup (group) -------------------------------------------
@@ -1399,6 +1401,55 @@ __device__ __forceinline__ VoxK make_voxk(const CamK &cam, const Grid &g, const 
   return vk;
 }
 
+// Copy the sh x sw4 pixel rectangle that starts at (row sr0, column sc0) of the frame's crop into the pool by LDS-DMA
+// (global_load_lds_dwordx4), NWV waves sharing the rows.  No VGPR staging and no ds_write pass: each wave
+// instruction moves up to 64 x 16 B straight into the row-major LDS image (lane i lands at base + 16*i, so lanes are
+// laid out as [row][4-pixel group]); all of a wave's pieces are in flight at once.  Sources need only 4-byte
+// alignment and EXEC-masked lanes leave their slot untouched (tools/probes/glds_probe.hip).  Completion is counted
+// in vmcnt: the caller waits for vmcnt(0) before its barrier.
+template <int NWV>
+__device__ __forceinline__ void stage_rect_dma(float *stage, const Frame &f, int64_t n_frame, int sc0, int sr0, int sh,
+                                               int sw4, int wave, int lane) {
+  const int ng = sw4 >> 2;                       // 4-pixel groups per row
+  const int64_t base_idx = (int64_t)sr0 * f.bw + sc0;
+  if (ng <= 64) {
+    const int rows_per = 64 / ng;                // rows one wave instruction covers
+    const int rsub = lane / ng, cg = lane - rsub * ng;
+    const int nblk = (sh + rows_per - 1) / rows_per;
+    for (int blk = wave; blk < nblk; blk += NWV) {
+      const int R0 = blk * rows_per;             // scalar
+      const int row = R0 + rsub;
+      const int64_t gi = base_idx + (int64_t)row * f.bw + 4 * cg;
+      const bool act = rsub < rows_per && row < sh;
+      float *ldst = stage + R0 * sw4;            // wave-uniform LDS base
+      if (act && gi + 3 < n_frame) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(f.depth + gi),
+                                         (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+      } else if (act) {  // the 16-byte piece would run past the end of the frame: element copies
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gi + e < n_frame) ldst[(rsub * ng + cg) * 4 + e] = f.depth[gi + e];
+      }
+    }
+  } else {
+    for (int row = wave; row < sh; row += NWV) {
+      for (int c4 = 0; c4 < ng; c4 += 64) {
+        const int cg = c4 + lane;
+        const int64_t gi = base_idx + (int64_t)row * f.bw + 4 * cg;
+        float *ldst = stage + row * sw4 + 4 * c4;  // wave-uniform
+        if (cg < ng && gi + 3 < n_frame) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(f.depth + gi),
+                                           (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+        } else if (cg < ng) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gi + e < n_frame) ldst[lane * 4 + e] = f.depth[gi + e];
+        }
+      }
+    }
+  }
+}
+
 // Per-frame tables (true divisions; (x,z)/(y,z) pairs spread over the T participating threads).
 template <int LAYOUT, bool AUG, class PG>
 __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &cam, const VoxK &vk, int R,
@@ -1605,12 +1656,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         // computed once before the frame loop and then occupies registers, or scratch, all through phase 1.
         int vt = gtid;
         asm volatile("" : "+v"(vt));
-        // ---- TSDF_FILL 0: stage the valid pixels' rectangle into the pool by LDS-DMA (global_load_lds_dwordx4) ----
-        // No VGPR staging and no ds_write pass: each wave instruction moves up to 64 x 16 B straight into
-        // the row-major LDS image (lane i lands at base + 16*i, so lanes are laid out as [row][4-pixel
-        // group]); all of a wave's pieces are in flight at once.  Sources need only 4-byte alignment
-        // and EXEC-masked lanes leave their slot untouched (tools/probes/glds_probe.hip).  The group holds
-        // the pool lock here (taken at the extents barrier), so the whole pool is its own.
+        // ---- TSDF_FILL 0: stage the valid pixels' rectangle into the pool by LDS-DMA.  The group holds the pool
+        // lock here (taken at the extents barrier), so the whole pool is its own.
         int mode = captured ? kFillSpans : kFillGlobal;
         // the staged image: the rectangle of valid pixels (the whole bounding box in the diagnostic build),
         // row-major from the start of the pool, rows padded to a multiple of 4 pixels (16-byte DMA pieces)
@@ -1620,48 +1667,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         const bool staged = !kCaptureFill && (int64_t)sw4 * sh <= L::kPoolFloats;  // group-uniform
         if (staged) {
           mode = kFillRect;
-          float *stage = lds.pool;
-          const int ng = sw4 >> 2;                       // 4-pixel groups per row
-          const int64_t n_frame = fh.off1 - fh.off0;     // elements in this frame's crop
-          const int64_t base_idx = (int64_t)sr0 * f.bw + sc0;
-          if (ng <= 64) {
-            const int rows_per = 64 / ng;                // rows one wave instruction covers
-            const int rsub = lane / ng, cg = lane - rsub * ng;
-            const int nblk = (sh + rows_per - 1) / rows_per;
-            for (int blk = gwave; blk < nblk; blk += kGWaves) {
-              const int R0 = blk * rows_per;             // scalar
-              const int row = R0 + rsub;
-              const int64_t gi = base_idx + (int64_t)row * f.bw + 4 * cg;
-              const bool act = rsub < rows_per && row < sh;
-              float *ldst = stage + R0 * sw4;            // wave-uniform LDS base
-              if (act && gi + 3 < n_frame) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(f.depth + gi),
-                    (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-              } else if (act) {  // the 16-byte piece would run past the end of the frame: element copies
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (gi + e < n_frame) ldst[(rsub * ng + cg) * 4 + e] = f.depth[gi + e];
-              }
-            }
-          } else {
-            for (int row = gwave; row < sh; row += kGWaves) {
-              for (int c4 = 0; c4 < ng; c4 += 64) {
-                const int cg = c4 + lane;
-                const int64_t gi = base_idx + (int64_t)row * f.bw + 4 * cg;
-                float *ldst = stage + row * sw4 + 4 * c4;  // wave-uniform
-                if (cg < ng && gi + 3 < n_frame) {
-                  __builtin_amdgcn_global_load_lds(
-                      (const __attribute__((address_space(1))) void *)(f.depth + gi),
-                      (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-                } else if (cg < ng) {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    if (gi + e < n_frame) ldst[lane * 4 + e] = f.depth[gi + e];
-                }
-              }
-            }
-          }
+          stage_rect_dma<kGWaves>(lds.pool, f, fh.off1 - fh.off0, sc0, sr0, sh, sw4, gwave, lane);
         }
         const VoxK vk = make_voxk(cam, g, f, ab, mode, DBG, sw4);
         const bool use_tab = !AUG && R <= kTabR;  // uniform
@@ -1790,7 +1796,22 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
 // the spans, places the grid, fills the tables — all redundantly, so no workgroup ever waits for another —
 // and voxelizes a.per slices of the slow axis.  Results are bit-identical to the fused kernel's: the
 // extents are min/max reductions (order-free) and the per-voxel code is the same.
-template <int RT, int LAYOUT, bool AUG>
+//
+// XCHG: the row stream itself is split as well.  Streaming a whole frame through ONE workgroup is a chain of
+// dependent cold misses (14.8 of the 17 us such a launch took), so here workgroup p of a frame streams only band p
+// of its rows, publishes its 10 partial extents in a mailbox in device memory — tagged with a number unique to the
+// launch on its stream — and collects the other bands' (min/max: order-free, so the result is bit-identical).
+// The wait is BOUNDED: a workgroup that does not see all mailboxes in time (its siblings are not resident yet,
+// e.g. behind another kernel) streams the whole frame itself, exactly like the non-XCHG form — nothing can
+// deadlock.  The valid-pixel rectangle then comes into LDS by LDS-DMA (its rows were just read by the siblings:
+// L2 hits).  The mailboxes are a lazily allocated per-stream workspace owned by the library (host: xchg_for());
+// launches that cannot have one (stream capture, too many streams) use the redundant form.
+constexpr int kXchgParts = 16;       // mailboxes per frame (upper bound of a.split)
+constexpr int kXchgFrames = 128;     // frames per split launch (n <= CUs/2)
+constexpr int kXchgBox = 16;         // floats per mailbox: 10 extents, tag, pad (64 bytes: one mailbox per line)
+constexpr int kXchgPolls = 4000;     // bound of the wait (x ~0.1 us)
+
+template <int RT, int LAYOUT, bool AUG, bool XCHG>
 __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const float *__restrict__ in_depth,
                                                          const int64_t *__restrict__ in_offsets,
                                                          const int32_t *__restrict__ in_headers,
@@ -1848,9 +1869,69 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
     status = TSDF_FRAME_BAD_HEADER;
   } else {
     float fin[kExt];
-    cap.on = want_vol && f.bw <= kMaxCapW && f.bh <= kMaxRows;
     auto sync_all = [&]() { __syncthreads(); };
-    phase1_extents<kWG / 64, AUG, true>(f, cam, 0, f.bh, pg.red, fin, wave, sync_all, cap, 0, xf);
+    bool have = false;  // workgroup-uniform: fin holds the frame's extents
+    if constexpr (XCHG) {
+      // ---- band `part` of the rows -> partial extents -> mailbox ----
+      const int S = a.split;
+      const int rb = (int)((int64_t)f.bh * part / S), re = (int)((int64_t)f.bh * (part + 1) / S);
+      phase1_extents<kWG / 64, AUG, false>(f, cam, rb, re, pg.red, fin, wave, sync_all, cap, 0, xf);
+      float *boxes = a.xchg + (int64_t)frame * (kXchgParts * kXchgBox);
+      // Every word goes out as an agent-scope atomic (written through to where the other XCDs' workgroups read it),
+      // the tag after the data has been acknowledged: a release without writing the whole L2 back.
+      if (tid == 0) {
+        unsigned int *box = reinterpret_cast<unsigned int *>(boxes + part * kXchgBox);
+#pragma unroll
+        for (int i = 0; i < kExt; ++i)
+          __hip_atomic_store(box + i, __float_as_uint(fin[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(box + kExt, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- collect the siblings' (wave 0: lane q watches mailbox q), bounded ----
+      if (wave == 0) {
+        const int lane = tid & 63;
+        const bool mine = lane < S;
+        const unsigned int *box = reinterpret_cast<const unsigned int *>(boxes + (mine ? lane : 0) * kXchgBox);
+        bool ready = !mine || lane == part;
+        for (int it = 0; it < kXchgPolls; ++it) {
+          if (!ready) ready = __hip_atomic_load(box + kExt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq;
+          if (__all(ready)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const bool all = __all(ready);
+        if (all) {
+          // the tag was written after its data was acknowledged, and these loads bypass this XCD's L2 as well
+          const bool use = mine && lane != part;
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const float v = __uint_as_float(__hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            fin[i] = vmin(fin[i], row0_min(use ? v : TSDF_INF));
+          }
+#pragma unroll
+          for (int i = 5; i < 10; ++i) {
+            const float v = __uint_as_float(__hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            fin[i] = vmax(fin[i], row0_max(use ? v : -TSDF_INF));
+          }
+          if (lane == 0) {  // (the row table is free in this form; `red` may still be read by a slow wave)
+#pragma unroll
+            for (int i = 0; i < kExt; ++i) pg.rowtab[i] = __float_as_uint(fin[i]);
+          }
+        }
+        if (lane == 0) ctl.cap_fail[1] = all ? 1 : 0;   // (a free word of the control block)
+      }
+      __syncthreads();
+      have = lds_load(&ctl.cap_fail[1]) != 0;
+      have = __builtin_amdgcn_readfirstlane(have);
+      if (have) {
+#pragma unroll
+        for (int i = 0; i < kExt; ++i) fin[i] = __uint_as_float(pg.rowtab[i]);
+      }
+    }
+    if (!have) {
+      // the redundant form: this workgroup streams the whole frame (and captures the valid row windows)
+      cap.on = !XCHG && want_vol && f.bw <= kMaxCapW && f.bh <= kMaxRows;
+      phase1_extents<kWG / 64, AUG, !XCHG>(f, cam, 0, f.bh, pg.red, fin, wave, sync_all, cap, 0, xf);
+    }
     ab = aabb_from_extents(fin);
     place_grid(ab, R, cam, a.grid_in, frame, g, status);
   }
@@ -1866,9 +1947,17 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
   }
   bool captured = cap.on && lds_load(&ctl.cap_fail[0]) == 0;
   captured = __builtin_amdgcn_readfirstlane(captured);
-  const VoxK vk = make_voxk(cam, g, f, ab, captured ? kFillSpans : kFillGlobal, false, 0);
+  int mode = captured ? kFillSpans : kFillGlobal;
+  const int sw = ab.c1 - ab.c0 + 1, sh = ab.r1 - ab.r0 + 1, sw4 = (sw + 3) & ~3;
+  const bool staged = XCHG && (int64_t)sw4 * sh <= L::kPoolFloats;
+  if (staged) {
+    mode = kFillRect;
+    stage_rect_dma<kWG / 64>(lds.pool, f, fh.off1 - fh.off0, ab.c0, ab.r0, sh, sw4, wave, tid & 63);
+  }
+  const VoxK vk = make_voxk(cam, g, f, ab, mode, false, sw4);
   const bool use_tab = !AUG && R <= kTabR;
-  fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, captured, xf, tid, kWG);
+  fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, mode == kFillSpans, xf, tid, kWG);
+  if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is counted in vmcnt
   __syncthreads();
   TSDF_STAMP(0, 6);
   const Tabs tb = make_tabs(pg);
@@ -1884,7 +1973,9 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
       phase2<LAYOUT, kWG, false>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, tid, sb, se, pm);
     }
   };
-  if (captured) {
+  if (mode == kFillRect) {
+    run2(LdsRect{(LdsSrc)lds.pool});
+  } else if (mode == kFillSpans) {
     run2((LdsSrc)lds.pool);
   } else {
     run2((GlobalSrc)(f.depth + vk.base));
@@ -1971,18 +2062,23 @@ struct StreamSlots {
   } e[kQueueSlots];
   int high = 0;  // entries [0, high) may be in use
   unsigned int *base = nullptr;  // device address of g_queue on this device
+  float *xchg = nullptr;         // split-kernel mailboxes (see xchg_for)
+  bool xchg_failed = false;
+  unsigned int xchg_seq[64] = {0};
 };
 StreamSlots g_slots[64];
 
-unsigned int *queue_word(int dev, hipStream_t s, bool release) {
-  if (dev < 0 || dev >= 64) return nullptr;
+// Index of the (device, stream) pair in the table, or -1 (capturing, no room, beyond the table).  `release` forgets
+// the pair instead.
+int stream_slot(int dev, hipStream_t s, bool release) {
+  if (dev < 0 || dev >= 64) return -1;
   if (!release) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
       (void)hipGetLastError();
-      return nullptr;
+      return -1;
     }
-    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    if (cs != hipStreamCaptureStatusNone) return -1;
   }
   StreamSlots &t = g_slots[dev];
   const bool per_thread = s == hipStreamPerThread;
@@ -1992,7 +2088,7 @@ unsigned int *queue_word(int dev, hipStream_t s, bool release) {
     void *p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_queue)) != hipSuccess || !p) {
       (void)hipGetLastError();
-      return nullptr;
+      return -1;
     }
     t.base = static_cast<unsigned int *>(p);
   }
@@ -2002,21 +2098,54 @@ unsigned int *queue_word(int dev, hipStream_t s, bool release) {
       if (t.e[i].s == s && t.e[i].tid == me) {
         if (release) {
           t.e[i].used = false;
-          return nullptr;
+          return -1;
         }
-        return t.base + i;
+        return i;
       }
     } else if (free_i < 0) {
       free_i = i;
     }
   }
-  if (release) return nullptr;
+  if (release) return -1;
   if (free_i < 0 && t.high < kQueueSlots) free_i = t.high++;
-  if (free_i < 0) return nullptr;
+  if (free_i < 0) return -1;
   t.e[free_i].used = true;
   t.e[free_i].s = s;
   t.e[free_i].tid = me;
-  return t.base + free_i;
+  return free_i;
+}
+
+unsigned int *queue_word(int dev, hipStream_t s) {
+  const int i = stream_slot(dev, s, false);
+  return i < 0 ? nullptr : g_slots[dev].base + i;
+}
+
+// Mailboxes of the split kernel's XCHG form for the launch being issued on (dev, s), and the tag it must use; null
+// when the launch cannot have any (stream capture, stream beyond the first kXchgSlots, allocation failed).  The
+// workspace (kXchgSlots x 128 KiB per device) is allocated and zeroed on the first small-batch call on the device —
+// the one time the library allocates; launches of one stream are ordered, so tags only ever grow inside a slot.
+constexpr int kXchgSlots = 64;
+constexpr size_t kXchgSlotFloats = (size_t)kXchgFrames * kXchgParts * kXchgBox;
+float *xchg_for(int dev, hipStream_t s, unsigned int *seq) {
+  const int i = stream_slot(dev, s, false);
+  if (i < 0 || i >= kXchgSlots) return nullptr;
+  StreamSlots &t = g_slots[dev];
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (!t.xchg) {
+    if (t.xchg_failed) return nullptr;
+    void *p = nullptr;
+    const size_t bytes = kXchgSlots * kXchgSlotFloats * sizeof(float);
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      t.xchg_failed = true;
+      return nullptr;
+    }
+    t.xchg = static_cast<float *>(p);
+  }
+  unsigned int v = ++t.xchg_seq[i];
+  if (v == 0) v = ++t.xchg_seq[i];  // 0 is what fresh mailboxes hold
+  *seq = v;
+  return t.xchg + (size_t)i * kXchgSlotFloats;
 }
 
 // Workgroups per frame and slices per workgroup for the split kernel (0: use the fused kernel).
@@ -2029,6 +2158,7 @@ void split_plan(int n, int R, int cus, int *split, int *per) {
   const int rounds = (R + sstep - 1) / sstep;
   int S = cus / n;
   if (S > rounds) S = rounds;
+  if (S > kXchgParts) S = kXchgParts;
   if (S < 2) return;
   const int p = ((rounds + S - 1) / S) * sstep;  // slices per workgroup
   S = (R + p - 1) / p;
@@ -2047,8 +2177,14 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
       a.split = S;
       a.per = per;
       a.queue = nullptr;
-      hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG>), dim3(a.n * S), dim3(kWG), 0, s, a, a.depth, a.offsets,
-                         a.headers, a.xforms);
+      a.xchg = a.n <= kXchgFrames ? xchg_for(dev, s, &a.seq) : nullptr;
+      if (a.xchg) {
+        hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG, true>), dim3(a.n * S), dim3(kWG), 0, s, a, a.depth,
+                           a.offsets, a.headers, a.xforms);
+      } else {
+        hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG, false>), dim3(a.n * S), dim3(kWG), 0, s, a, a.depth,
+                           a.offsets, a.headers, a.xforms);
+      }
       return hipGetLastError();
     }
   }
@@ -2056,7 +2192,7 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
   const int grid = a.n < cus ? a.n : cus;
   a.split = 0;
   a.per = a.R;
-  a.queue = a.n > grid * kGroups ? queue_word(dev, s, false) : nullptr;  // no dynamic frames: no word needed
+  a.queue = a.n > grid * kGroups ? queue_word(dev, s) : nullptr;  // no dynamic frames: no word needed
   hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
                      a.headers, a.xforms);
   return hipGetLastError();
@@ -2275,7 +2411,7 @@ int tsdf_stream_release(void *hip_stream) {
     (void)hipGetLastError();
     return TSDF_OK;
   }
-  (void)queue_word(dev, static_cast<hipStream_t>(hip_stream), true);
+  (void)stream_slot(dev, static_cast<hipStream_t>(hip_stream), true);
   return TSDF_OK;
 }
 

@@ -857,3 +857,54 @@ def test_graphs_and_eager_launches_share_nothing(pkg, synth):
     torch.cuda.synchronize()
     for o in ring:
         assert torch.equal(o.tsdf, ref_b.tsdf)
+
+
+def test_split_kernel_exchange_under_contention(pkg, synth):
+    """Small batches split a frame's ROWS over several workgroups that exchange partial extents through per-stream
+    mailboxes, with a bounded wait and a redundant fallback.  Six streams each fire 40 unsynchronised small-batch
+    launches (64 frames x 4 workgroups = the whole chip per launch, so siblings are often not co-resident and
+    the fallback runs), interleaved with large fused launches: every result is bit-identical to a quiet run; the
+    same batches captured into a graph (no mailboxes there) as well."""
+    d = dev()
+    sets = []
+    for k, (kind, n) in enumerate((("full", 64), ("crop", 16), ("full", 128), ("crop", 100), ("full", 3), ("crop", 64))):
+        depth, off, hdr = synth.synth_batch(n, kind, seed0=9500 + 200 * k)
+        t = tuple(torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+        ref = pkg.voxelize(*t)
+        torch.cuda.synchronize()
+        oref = oracle.voxelize(depth, off, hdr, R=32, n_threads=8)
+        assert np.abs(ref.tsdf.cpu().numpy() - oref["tsdf"]).max() <= TOL
+        np.testing.assert_array_equal(ref.mid_p.cpu().numpy(), oref["mid_p"])
+        sets.append((t, ref, [pkg.voxelize(*t) for _ in range(2)]))
+    big = tuple(torch.from_numpy(a).to(d) for a in synth.synth_batch(1500, "crop", seed0=9900))
+    big_ref = pkg.voxelize(*big)
+    big_out = pkg.voxelize(*big)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(d) for _ in sets]
+    bs = torch.cuda.Stream(d)
+    for rnd in range(40):
+        for (t, ref, outs), st in zip(sets, streams):
+            with torch.cuda.stream(st):
+                pkg.voxelize(*t, out=outs[rnd & 1])
+        if rnd % 5 == 0:
+            with torch.cuda.stream(bs):
+                pkg.voxelize(*big, out=big_out)
+        if rnd % 8 == 7:
+            torch.cuda.synchronize()
+            for t, ref, outs in sets:
+                for o in outs:
+                    assert torch.equal(o.tsdf, ref.tsdf) and torch.equal(o.max_l, ref.max_l), rnd
+                    o.tsdf.zero_()
+            assert torch.equal(big_out.tsdf, big_ref.tsdf)
+    torch.cuda.synchronize()
+    # captured: the redundant form
+    t, ref, outs = sets[0]
+    g = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream(d)
+    with torch.cuda.stream(cs):
+        with torch.cuda.graph(g, stream=cs):
+            pkg.voxelize(*t, out=outs[0])
+    outs[0].tsdf.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].tsdf, ref.tsdf) and torch.equal(outs[0].mid_p, ref.mid_p)

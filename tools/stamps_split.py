@@ -27,6 +27,7 @@ for kind in ("full", "crop"):
         assert L.tsdf_debug_read_stamps(buf.ctypes.data, buf.size) == buf.size
         s = buf.reshape(BL, FR, SL).astype(np.int64)[: min(512, n * 8), 0, :]
         t0 = s[:, 0].min()
-        r = (s[:, [0, 4, 6, 9, 11]] - t0) / 100.0
-        print(f"{kind} n={n}: {s.shape[0]} workgroups; medians (us) start {np.median(r[:,0]):.2f}  extents {np.median(r[:,1]):.2f}  "
-              f"tables {np.median(r[:,2]):.2f}  voxels issued {np.median(r[:,3]):.2f}  stores done {np.median(r[:,4]):.2f}  (max end {r[:,4].max():.2f})")
+        r = (s[:, [0, 1, 3, 4, 6, 9, 11]] - t0) / 100.0
+        m = np.median(r, axis=0)
+        print(f"{kind} n={n}: {s.shape[0]} workgroups; medians (us) start {m[0]:.2f}  rows streamed {m[1]:.2f}  partials in LDS {m[2]:.2f}  "
+              f"extents known {m[3]:.2f}  staged+tables {m[4]:.2f}  voxels issued {m[5]:.2f}  stores done {m[6]:.2f}  (max end {r[:,6].max():.2f})")
