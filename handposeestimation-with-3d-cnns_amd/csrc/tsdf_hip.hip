@@ -48,6 +48,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -1151,6 +1152,8 @@ struct KArgs {
   int split, per;         // split kernel: workgroups per frame, slow-axis slices per workgroup
   float *xchg;            // split kernel: this stream's mailboxes for partial extents, or null (see the kernel)
   unsigned int seq;       // ... and the number this launch tags them with
+  int polls;              // ... and the bound of the wait for them (kXchgPolls; tests set TSDF_XCHG_POLLS=0 to
+                          // force every workgroup onto the fallback)
 };
 
 // ---- synchronisation inside one half-workgroup (group) -------------------------------------------
@@ -1893,7 +1896,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
         const bool mine = lane < S;
         const unsigned int *box = reinterpret_cast<const unsigned int *>(boxes + (mine ? lane : 0) * kXchgBox);
         bool ready = !mine || lane == part;
-        for (int it = 0; it < kXchgPolls; ++it) {
+        for (int it = 0; it < a.polls; ++it) {
           if (!ready) ready = __hip_atomic_load(box + kExt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq;
           if (__all(ready)) break;
           __builtin_amdgcn_s_sleep(1);
@@ -2178,6 +2181,11 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
       a.per = per;
       a.queue = nullptr;
       a.xchg = a.n <= kXchgFrames ? xchg_for(dev, s, &a.seq) : nullptr;
+      static const int polls = [] {
+        const char *e = getenv("TSDF_XCHG_POLLS");
+        return e ? atoi(e) : kXchgPolls;
+      }();
+      a.polls = polls;
       if (a.xchg) {
         hipLaunchKernelGGL((tsdf_split_kernel<RT, LAYOUT, AUG, true>), dim3(a.n * S), dim3(kWG), 0, s, a, a.depth,
                            a.offsets, a.headers, a.xforms);

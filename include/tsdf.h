@@ -13,9 +13,14 @@
  *   - The caller allocates and owns every buffer.  `d_` pointers are DEVICE
  *     pointers (hipMalloc / torch CUDA tensors) valid on the current device.
  *   - Calls enqueue work on `hip_stream` (a hipStream_t, NULL = default stream)
- *     and return WITHOUT synchronising.  They allocate nothing, never print and
- *     never throw; they are re-entrant for distinct streams and may be captured
- *     into a hipGraph.  Work-queue ownership (the kernels hand frames to their
+ *     and return WITHOUT synchronising.  They never print and never throw; they are
+ *     re-entrant for distinct streams and may be captured into a hipGraph.  They
+ *     allocate nothing — with one exception that happens at most once per device:
+ *     the first call with a small batch (n <= CUs/2) outside stream capture allocates
+ *     and zeroes an 8 MiB workspace (mailboxes through which the workgroups that share
+ *     a frame exchange partial extents; 128 KiB per stream for the first 64 streams),
+ *     which synchronises the device that one time.  Captured launches and later
+ *     streams never use it.  Work-queue ownership (the kernels hand frames to their
  *     workgroups dynamically): an eager launch uses a device-side queue word owned by
  *     its (device, stream) pair — launches on one stream execute in order, so the word
  *     is never shared, however many launches are in flight; the library keeps one word

@@ -908,3 +908,32 @@ def test_split_kernel_exchange_under_contention(pkg, synth):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(outs[0].tsdf, ref.tsdf) and torch.equal(outs[0].mid_p, ref.mid_p)
+
+
+def test_split_kernel_fallback_when_siblings_never_answer(tmp_path):
+    """TSDF_XCHG_POLLS=0 makes every workgroup of the exchange form give up waiting at once and stream the whole
+    frame itself: the path a workgroup takes when its siblings are not resident.  Same results (child process:
+    the bound is read once per process)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import oracle
+pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
+synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+d = torch.device("cuda:0")
+for kind, n, R in (("full", 1, 32), ("crop", 16, 32), ("full", 40, 32), ("crop", 5, 64)):
+    depth, off, hdr = synth.synth_batch(n, kind, seed0=123)
+    out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d), torch.from_numpy(hdr).to(d), res=R)
+    torch.cuda.synchronize()
+    ref = oracle.voxelize(depth, off, hdr, R=R, n_threads=8)
+    assert np.array_equal(out.max_l.cpu().numpy(), ref["max_l"]) and np.array_equal(out.mid_p.cpu().numpy(), ref["mid_p"])
+    assert np.abs(out.tsdf.cpu().numpy() - ref["tsdf"]).max() <= 1e-5
+print("FALLBACK-OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TSDF_XCHG_POLLS="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert "FALLBACK-OK" in r.stdout, r.stdout + r.stderr
