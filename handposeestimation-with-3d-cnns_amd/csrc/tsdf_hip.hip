@@ -1810,7 +1810,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
 // L2 hits).  The mailboxes are a lazily allocated per-stream workspace owned by the library (host: xchg_for());
 // launches that cannot have one (stream capture, too many streams) use the redundant form.
 constexpr int kXchgParts = 16;       // mailboxes per frame (upper bound of a.split)
-constexpr int kXchgFrames = 128;     // frames per split launch (n <= CUs/2)
+constexpr int kXchgFrames = 128;     // frames per split launch at most (n <= CUs/2)
 constexpr int kXchgBox = 16;         // floats per mailbox: 10 extents, tag, pad (64 bytes: one mailbox per line)
 constexpr int kXchgPolls = 4000;     // bound of the wait (x ~0.1 us)
 
@@ -2155,11 +2155,19 @@ float *xchg_for(int dev, hipStream_t s, unsigned int *seq) {
 void split_plan(int n, int R, int cus, int *split, int *per) {
   *split = 0;
   *per = R;
-  if (n * 2 > cus) return;
+  // (experiments: TSDF_SPLIT_MAXN overrides the batch size up to which frames are split; beyond CUs/2 the fused
+  // kernel measured faster: 256 full frames 38 us fused, 46 us split — tools/exp_split_threshold.py)
+  static const int max_n = [] {
+    const char *e = getenv("TSDF_SPLIT_MAXN");
+    return e ? atoi(e) : -1;
+  }();
+  const int limit = max_n >= 0 ? max_n : cus / 2;
+  if (n > limit || n > kXchgFrames) return;
   const int G = R * (R / 4);
   const int sstep = (G <= kWG && kWG % G == 0) ? kWG / G : 1;  // slices one pass of the workgroup covers
   const int rounds = (R + sstep - 1) / sstep;
   int S = cus / n;
+  if (S < 2) S = 2;
   if (S > rounds) S = rounds;
   if (S > kXchgParts) S = kXchgParts;
   if (S < 2) return;
