@@ -17,6 +17,10 @@ if mode.startswith("aug"):       # aug32 / aug64: the fused-augmentation kernel 
     oa = pkg.voxelize_aug(td, to, th, xf, res=R)
     for _ in range(6):
         pkg.voxelize_aug(td, to, th, xf, res=R, out=oa)
+elif mode == "r64":              # 1024 full frames -> 64^3, plain
+    o64 = pkg.voxelize(td, to, th, res=64)
+    for _ in range(6):
+        pkg.voxelize(td, to, th, res=64, out=o64)
 elif mode == "crop":             # 1024 MSRA-like crops
     depth, off, hdr = synth.synth_batch(1024, "crop", seed0=0)
     td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
