@@ -1027,6 +1027,7 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
     const double vpy = oy + (double)y * vl;
+    const double vpy_it = vpy * vk.it;  // centre coordinates pre-scaled by 1/trunc_dis, as in the plain pass
     const double ty0 = taby[3 * y], ty1 = taby[3 * y + 1], ty2 = taby[3 * y + 2];
     // The inverse map is ((A_i0 x' + A_i1 y') + A_i2 z') + b_i with separately rounded products.  Along the lane's
     // fixed axes the first sum does not change from slice to slice: LAYOUT 0 (x, y fixed per lane) keeps
@@ -1094,7 +1095,7 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
           wx[j] = ((double)ex[j] + vk.dxc) * q2[j];                                // :44 (pix_x - cx, exact)
           wy[j] = -((double)ry[j] + vk.dyc) * q2[j];                               // :45
           az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
-          tz[j] = (vpz[j] - az[j]) * vk.it;                                        // :49
+          tz[j] = __builtin_fma(-az[j], vk.it, vpz[j] * vk.it);                    // :49 (v'_z - w'_z)/trunc
           any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
           sv[j] = ok[j] ? (az[j] > vpz[j] ? -1.0f : 1.0f) : 0.0f;                  // w'_z > v'_z  :65
         }
@@ -1109,7 +1110,8 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
             const double wz = -(double)pd[j];
             const double ax = affine_row(fwd + 0, wx[j], wy[j], wz);
             const double ay = affine_row(fwd + 4, wx[j], wy[j], wz);
-            const double tx = (vpx[j] - ax) * vk.it, ty = (vpy - ay) * vk.it;      // :47-48
+            const double tx = __builtin_fma(-ax, vk.it, vpx[j] * vk.it);           // :47
+            const double ty = __builtin_fma(-ay, vk.it, vpy_it);                   // :48
             const double s2 = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));
             const bool nearv = s2 <= 1.0;                                          // :54
             const float m0 = vminabs((float)tx, 1.0f);
