@@ -997,16 +997,15 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
 // distances are taken between v' and T(w).  The projection no longer factorises, so there are no pixel
 // tables and q = -F / v_z is one true division per voxel; what does factorise is the inverse map: its
 // three products per row, A_i0*v'_x, A_i1*v'_y, A_i2*v'_z, depend on one grid index each and are
-// tabulated per frame (atab, 9*R doubles), leaving ((a + b) + c) + d — the oracle's exact rounding order.
-// atab layout: [axis][index][row] = fl(inv[4*row + axis] * (ori_axis + index*voxel_len)).
+// tabulated per frame (atab, 9*R doubles), leaving (a + b) + (c + d) — the oracle's exact rounding order.
+// atab layout: [axis][index][row] = fl(inv[4*row + axis] * (ori_axis + index*voxel_len)), the z entries + b_row.
 template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                            const double *xf, const Tabs &tb, const SrcP src,
                                            const GlobalOut out, const int tid, const int sb, const int se) {
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
-  const double *fwd = xf, *inv = xf + 12;
-  const double bi0 = inv[3], bi1 = inv[7], bi2 = inv[11];
+  const double *fwd = xf;
   const LdsCD tabx = tb.atab, taby = tb.atab + 3 * R, tabz = tb.atab + 6 * R;
   const int R4 = R / 4;
   const int G = R * R4;
@@ -1029,9 +1028,11 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     const double vpy = oy + (double)y * vl;
     const double vpy_it = vpy * vk.it;  // centre coordinates pre-scaled by 1/trunc_dis, as in the plain pass
     const double ty0 = taby[3 * y], ty1 = taby[3 * y + 1], ty2 = taby[3 * y + 2];
-    // The inverse map is ((A_i0 x' + A_i1 y') + A_i2 z') + b_i with separately rounded products.  Along the lane's
-    // fixed axes the first sum does not change from slice to slice: LAYOUT 0 (x, y fixed per lane) keeps
-    // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps A_i1 y' and A_i2 z'.
+    // The inverse map is (A_i0 x' + A_i1 y') + (A_i2 z' + b_i), every product and sum rounded separately (the
+    // oracle's affine3).  Both brackets depend on grid indices only: the z table holds (A_i2 z' + b_i), and the
+    // bracket that does not change from slice to slice stays in registers — LAYOUT 0 (x, y fixed per lane) keeps
+    // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps the z bracket — so a voxel costs ONE add
+    // per row of the map.
     double pre[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1071,9 +1072,9 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         const int x = LAYOUT == 0 ? f4i + j : sl, z = LAYOUT == 0 ? sl : f4i + j;
         vpx[j] = ox + (double)x * vl;
         vpz[j] = oz + (double)z * vl;
-        const double vx = LAYOUT == 0 ? (pre[j][0] + sl0) + bi0 : (sl0 + pre[j][0]) + bi0;   // v = T^-1(v')
-        const double vy = LAYOUT == 0 ? (pre[j][1] + sl1) + bi1 : (sl1 + pre[j][1]) + bi1;
-        const double vz = LAYOUT == 0 ? (pre[j][2] + sl2) + bi2 : (sl2 + pre[j][2]) + bi2;
+        const double vx = pre[j][0] + sl0;   // v = T^-1(v') = (A_i0 x' + A_i1 y') + (A_i2 z' + b_i)
+        const double vy = pre[j][1] + sl1;
+        const double vz = pre[j][2] + sl2;
         const double q = -cam.focal / vz;                                        // :30
         ex[j] = trunc_i32(mul_then_add(vx, q, cam.cx)) - vk.px0;                 // :31, relative; may lie outside
         ry[j] = trunc_i32(mul_then_add(-vy, q, cam.cy)) - vk.py0;                // :32
@@ -1476,7 +1477,8 @@ __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &c
     for (int e = vt; e < 9 * R; e += T) {
       const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
       const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
-      pg.atab[e] = inv[4 * row + axis] * (o_a + (double)i * vl);
+      const double prod = inv[4 * row + axis] * (o_a + (double)i * vl);
+      pg.atab[e] = axis == 2 ? prod + inv[4 * row + 3] : prod;   // the z entries carry the translation
     }
   }
   if (use_tab) {

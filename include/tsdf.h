@@ -171,7 +171,7 @@ int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_
  *   of that grid is mapped back (T^-1), projected and gathered as in tsdf_voxelize_hip, the surface
  *   point is mapped forward and the truncated distances are taken between v' and T(w).
  *   T is evaluated as fma(A_i0, x, fma(A_i1, y, fma(A_i2, z, b_i))) per row, T^-1 with separately rounded
- *   products summed left to right (float64 both).
+ *   products and sums grouped as (A_i0 x + A_i1 y) + (A_i2 z + b_i) (float64 both).
  *   With the identity map the result equals tsdf_voxelize_hip.  max_l / mid_p are in the mapped frame.
  */
 int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,

@@ -268,17 +268,22 @@ int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32
  *
  * xf = double[24] per frame: forward affine T(p) = A p + b as rows {A_i0, A_i1, A_i2, b_i} (12 values),
  * then its inverse in the same form (12 values).  Every product/sum below is a separately rounded
- * float64 operation, in the order written.
+ * float64 operation, in the order written (see affine3 / affine3_fwd).
  *   cloud:  p' = T(p) for the back-projected point p of every valid pixel (A.1, before the float32
  *           rounding), then rounded to float32 for the AABB -> glue as in the plain path;
  *   voxel:  centre v' lives in the augmented frame; v = T^-1(v') is projected (pre/tsdf_numba.py:30-32),
  *           the surface point w of that pixel (:43-46) is mapped forward, w' = T(w), and the
  *           truncated distances (:47-68) are taken between v' and w'.
  */
-/* Inverse map (voxel centre back into the camera frame): products rounded one by one, summed left to right —
- * a form whose products depend on one grid index each, so an implementation may tabulate them. */
+/* Inverse map (voxel centre back into the camera frame): every product and sum rounded separately, grouped as
+ * (A_i0 x + A_i1 y) + (A_i2 z + b_i) — both brackets depend on grid indices only, so an implementation may
+ * tabulate / hoist them and pay one addition per voxel and row.  The identity map returns p exactly. */
 static void affine3(const double *m, const double *p, double *o) {
-  for (int i = 0; i < 3; ++i) o[i] = ((m[4 * i] * p[0] + m[4 * i + 1] * p[1]) + m[4 * i + 2] * p[2]) + m[4 * i + 3];
+  for (int i = 0; i < 3; ++i) {
+    volatile double a = m[4 * i] * p[0], b = m[4 * i + 1] * p[1], c = m[4 * i + 2] * p[2];
+    volatile double ab = a + b, cd = c + m[4 * i + 3];
+    o[i] = ab + cd;
+  }
 }
 
 /* Forward map (camera-frame point into the augmented frame): a fused chain, one rounding per step.  With the
