@@ -2070,7 +2070,7 @@ struct StreamSlots {
   int high = 0;  // entries [0, high) may be in use
   unsigned int *base = nullptr;  // device address of g_queue on this device
   float *xchg = nullptr;         // split-kernel mailboxes (see xchg_for)
-  bool xchg_failed = false;
+  int xchg_failures = 0;
   unsigned int xchg_seq[64] = {0};
 };
 StreamSlots g_slots[64];
@@ -2139,12 +2139,18 @@ float *xchg_for(int dev, hipStream_t s, unsigned int *seq) {
   StreamSlots &t = g_slots[dev];
   std::lock_guard<std::mutex> lock(t.mu);
   if (!t.xchg) {
-    if (t.xchg_failed) return nullptr;
-    void *p = nullptr;
+    if (t.xchg_failures >= 8) return nullptr;  // (e.g. another thread's stream capture forbids allocation right now:
+    void *p = nullptr;                          //  try again on a later call, but not forever)
     const size_t bytes = kXchgSlots * kXchgSlotFloats * sizeof(float);
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+    if (hipMalloc(&p, bytes) != hipSuccess) {
       (void)hipGetLastError();
-      t.xchg_failed = true;
+      ++t.xchg_failures;
+      return nullptr;
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p);
+      ++t.xchg_failures;
       return nullptr;
     }
     t.xchg = static_cast<float *>(p);
