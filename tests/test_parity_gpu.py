@@ -937,3 +937,44 @@ print("FALLBACK-OK")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TSDF_XCHG_POLLS="0"), capture_output=True,
                        text=True, timeout=300)
     assert "FALLBACK-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_host_threads_launch_concurrently(pkg, synth):
+    """The library's host state (stream table, queue words, mailbox tags) is shared by threads: four host threads,
+    each with its own stream, interleave large (work queue) and small (mailbox exchange) launches; every result is
+    bit-identical to a quiet run."""
+    import threading
+
+    d = dev()
+    big = tuple(torch.from_numpy(a).to(d) for a in synth.synth_batch(900, "crop", seed0=4100))
+    small = tuple(torch.from_numpy(a).to(d) for a in synth.synth_batch(24, "full", seed0=4200))
+    ref_big, ref_small = pkg.voxelize(*big), pkg.voxelize(*small)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(d)
+            ob, os_ = pkg.voxelize(*big), pkg.voxelize(*small)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                for it in range(60):
+                    pkg.voxelize(*big, out=ob)
+                    pkg.voxelize(*small, out=os_)
+                    if it % 20 == 19:
+                        st.synchronize()
+                        if not (torch.equal(ob.tsdf, ref_big.tsdf) and torch.equal(os_.tsdf, ref_small.tsdf)
+                                and torch.equal(os_.mid_p, ref_small.mid_p)):
+                            errors.append((k, it))
+                        ob.tsdf.zero_()
+                        os_.tsdf.zero_()
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
