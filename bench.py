@@ -8,8 +8,10 @@
 One "step" = one fused launch of the voxelizer over the rank's batch of 1024 synthetic
 320x240 full-frame depth crops (BASELINE.json configs[1]), inputs already resident in HBM.
 Frames are independent, so N GPUs = N ranks each voxelizing its own 1024-frame shard
-(weak scaling, no data-path collective; RCCL is used only for the start/stop barrier and
-the max-over-ranks of the elapsed time).  Rank 0 prints ONE JSON line.
+(weak scaling, no data-path collective).  RCCL carries the process group, the rendezvous and the
+max-over-ranks of the elapsed time; the barriers that bracket the timed region are node-local
+(NodeBarrier: /dev/shm, microseconds) because a collective barrier costs 0.2-0.4 ms — a tenth of the
+driver's 20-step timed region — and would be charged to N>1 only.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline     the fused kernel against the HBM roofline: algorithmic bytes per launch
@@ -87,6 +89,51 @@ def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
                   f"{nN} frames in {tN:.2f} s on {used} OpenMP threads; single thread {n1} frames in {t1:.2f} s",
         "single_thread_value": round(fps1, 1),
     }
+
+
+class NodeBarrier:
+    """Barrier for the ranks of ONE node through a small file in /dev/shm: every rank publishes the number of the
+    barrier it has reached in its own 64-byte slot and spins until all slots show it (a few microseconds, against
+    0.2-0.4 ms for a collective barrier — 10 % of the driver's 20-step timed region).  The frames shard with no
+    exchange, so the only thing a barrier does here is bracket the timed region; RCCL still carries the process
+    group, the one-time rendezvous below and the max-over-ranks of the elapsed time.  `ok` is False (and the caller
+    keeps using the collective barrier) when the ranks do not see each other's writes within the timeout, e.g. ranks
+    in different /dev/shm namespaces."""
+
+    def __init__(self, dist, rank, world, collective_barrier, timeout_s=5.0):
+        self.rank, self.world, self.n, self.ok = rank, world, 0, False
+        run = os.environ.get("TORCHELASTIC_RUN_ID", "x") + "_" + os.environ.get("MASTER_PORT", "0")
+        self.path = f"/dev/shm/tsdf_bench_barrier_{run}"
+        try:
+            if rank == 0:
+                with open(self.path, "wb") as f:
+                    f.write(b"\0" * (64 * world))
+            collective_barrier()  # the file exists and is zeroed before anyone maps it
+            self.slots = np.memmap(self.path, dtype=np.int64, mode="r+", shape=(world, 8))
+            good = self._wait(timeout_s)
+        except OSError:
+            good = False
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        self.ok = bool(flag.item())
+        collective_barrier()
+        if rank == 0:
+            try:
+                os.unlink(self.path)  # the mappings stay valid
+            except OSError:
+                pass
+
+    def _wait(self, timeout_s=None):
+        self.n += 1
+        self.slots[self.rank, 0] = self.n
+        t0 = time.perf_counter()
+        while int(self.slots[:, 0].min()) < self.n:
+            if timeout_s is not None and time.perf_counter() - t0 > timeout_s:
+                return False
+        return True
+
+    def __call__(self):
+        self._wait()
 
 
 def _time_launches(fn, k, warm=3):
@@ -272,10 +319,15 @@ def main():
     torch.cuda.synchronize()
     assert bool((out.status == 0).all())
 
+    def collective_barrier():
+        dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
+
+    node_barrier = NodeBarrier(dist, rank, world, collective_barrier) if dist is not None else None
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
+            node_barrier() if node_barrier.ok else collective_barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -337,6 +389,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "barrier": (("node (/dev/shm)" if node_barrier.ok else "collective") if dist is not None else "none (one process)"),
             "config": {
                 "workload": "BASELINE configs[1]: batch 1024 synthetic 320x240 full-frame depth crops -> 32^3 "
                             "3-channel TSDF per GPU, inputs resident in HBM, one fused launch per step",
