@@ -978,3 +978,24 @@ def test_host_threads_launch_concurrently(pkg, synth):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("J", [1, 7, 170])
+def test_label_normalisation_other_joint_counts(pkg, synth, J):
+    """n_joints is an argument (MSRA: 21): 1, 7 and the maximum 170 joints per frame, fused and alone, against the
+    oracle; 171 is rejected."""
+    d = dev()
+    n = 40
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=2700)
+    ref = oracle.voxelize(depth, off, hdr, R=32, n_threads=8)
+    gt = (np.repeat(ref["mid_p"], J, axis=0).reshape(n, J, 3) +
+          np.random.default_rng(J).normal(0, 60, (n, J, 3))).astype(np.float32).reshape(n, 3 * J)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    out, nor = pkg.voxelize_labels(td, to, th, torch.from_numpy(gt).to(d))
+    torch.cuda.synchronize()
+    want = oracle.normalize_joints(gt, ref["max_l"], ref["mid_p"])
+    np.testing.assert_array_equal(nor.cpu().numpy(), want)
+    np.testing.assert_array_equal(pkg.normalize_joints(torch.from_numpy(gt).to(d), out.max_l, out.mid_p).cpu().numpy(), want)
+    if J == 170:
+        with pytest.raises(ValueError):
+            pkg.voxelize_labels(td, to, th, torch.zeros((n, 3 * 171), device=d))
