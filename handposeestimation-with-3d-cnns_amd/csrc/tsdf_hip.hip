@@ -204,6 +204,30 @@ __device__ __forceinline__ double div_by_focal(double d, const CamK &k) {
   return __builtin_fma(r, k.inv_focal, q0);
 }
 
+// -F / vz for the augmented projection (a true division: the divisor changes from voxel to voxel).
+//   FAST = false: the compiler's IEEE division (2 v_div_scale, v_rcp, 4 fma, mul, fma, v_div_fmas, v_div_fixup).
+//   FAST = true:  the same sequence without its three scaling / fix-up instructions.  Those are the identity while
+//                 neither operand nor the quotient comes near the ends of the exponent range, so the result is the
+//                 same bit for bit; the caller proves 2^-600 < |vz| < 2^600 for a lane's whole column of voxels and
+//                 2^-100 < F < 2^100 before choosing this form (phase2_aug), anything else takes the division.
+template <bool FAST>
+__device__ __forceinline__ double neg_focal_over(double vz, const CamK &k) {
+  if constexpr (!FAST) {
+    return -k.focal / vz;
+  } else {
+    const double n = -k.focal;
+    double r = __builtin_amdgcn_rcp(vz);
+    r = __builtin_fma(r, __builtin_fma(-vz, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-vz, r, 1.0), r);
+    const double q0 = n * r;
+    return __builtin_fma(__builtin_fma(-vz, q0, n), r, q0);
+  }
+}
+__device__ __forceinline__ bool mid_range(double v, double lo, double hi) {  // false for NaN
+  const double a = __builtin_fabs(v);
+  return a > lo && a < hi;
+}
+
 // A.1 x: f32( (f64(d)/F) * (x - cx) )      pre/tsdf_numba.py:91-92,95
 __device__ __forceinline__ float backproject_x(float d, int x, const CamK &k) {
   const double q = div_by_focal((double)d, k);
@@ -1003,6 +1027,7 @@ template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                            const double *xf, const Tabs &tb, const SrcP src,
                                            const GlobalOut out, const int tid, const int sb, const int se) {
+  if (se <= sb) return;  // (uniform) nothing to do; the end-slice lookups below assume one slice at least
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
   const double *fwd = xf;
@@ -1048,6 +1073,20 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         pre[j][2] = tzp[2];
       }
     }
+    // Which division (neg_focal_over): v_z of a lane's voxel is fl(pre + slice term), monotone in the slice index
+    // (every rounding is), so its two end slices bound it; same sign and mid-range at both ends -> mid-range throughout.
+    bool mild = mid_range(cam.focal, 0x1p-100, 0x1p100);
+    {
+      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 3 * sb, thi = (LAYOUT == 0 ? tabz : tabx) + 3 * (se - 1);
+      const double s_lo = LAYOUT == 0 ? tlo[2] : tlo[2] + ty2, s_hi = LAYOUT == 0 ? thi[2] : thi[2] + ty2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double za = pre[j][2] + s_lo, zb = pre[j][2] + s_hi;
+        mild = mild && mid_range(za, 0x1p-600, 0x1p600) && mid_range(zb, 0x1p-600, 0x1p600) && ((za > 0.0) == (zb > 0.0));
+      }
+    }
+    auto slices = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     for (int sl = sb + s0; sl < se; sl += sstep) {
       // ---- project the 4 voxels and gather their depths ----
       int ex[4], ry[4];
@@ -1075,7 +1114,7 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         const double vx = pre[j][0] + sl0;   // v = T^-1(v') = (A_i0 x' + A_i1 y') + (A_i2 z' + b_i)
         const double vy = pre[j][1] + sl1;
         const double vz = pre[j][2] + sl2;
-        const double q = -cam.focal / vz;                                        // :30
+        const double q = neg_focal_over<FAST>(vz, cam);                          // :30  -F / v_z
         ex[j] = trunc_i32(mul_then_add(vx, q, cam.cx)) - vk.px0;                 // :31, relative; may lie outside
         ry[j] = trunc_i32(mul_then_add(-vy, q, cam.cy)) - vk.py0;                // :32
         bool inb;
@@ -1128,6 +1167,12 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
       store_vol4(out + e, o0);
       store_vol4(out + R3 + e, o1);
       store_vol4(out + 2 * R3 + e, o2);
+    }
+    };
+    if (__all(mild)) {
+      slices(std::true_type{});
+    } else {
+      slices(std::false_type{});
     }
   }
 }

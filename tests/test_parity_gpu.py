@@ -999,3 +999,37 @@ def test_label_normalisation_other_joint_counts(pkg, synth, J):
     if J == 170:
         with pytest.raises(ValueError):
             pkg.voxelize_labels(td, to, th, torch.zeros((n, 3 * 171), device=d))
+
+
+def test_augmented_projection_division_forms(pkg, synth):
+    """The augmented pass computes -F / v_z per voxel: a lane whose column of voxels stays in the middle of the exponent
+    range takes a shortened form of the division sequence, everything else the full IEEE division (neg_focal_over in
+    the kernel).  Inverse maps that push v_z across zero, to exactly zero, to 1e302, to 1e-200 and to NaN go through
+    the full form, ordinary ones through the short one: all must agree with the oracle's division."""
+    d = dev()
+    n = 7
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=3100)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
+    xf, _ = pkg.augment.random_affines(mid, rng=11)
+    xf = xf.copy().reshape(n, 2, 3, 4)          # [frame][forward, inverse][row][A_i0 A_i1 A_i2 b_i]
+    inv = xf[:, 1]
+    inv[1, 2] = [0.0, 0.0, 1.0, -float(mid[1, 2])]          # v_z = z' - mid_z: crosses zero inside the grid
+    inv[2, 2] = [0.0, 0.0, 0.0, 0.0]                        # v_z == 0 everywhere: q = -inf
+    inv[3, 2] *= 1e300                                      # |v_z| ~ 1e302
+    inv[4, 2] *= 1e-202                                     # |v_z| ~ 1e-200
+    inv[5, 2, 1] = np.nan                                   # v_z NaN
+    xf = xf.reshape(n, 24)                                  # frames 0 and 6: ordinary maps
+    txf = torch.from_numpy(xf).to(d)
+    for R, layout in ((32, "czyx"), (32, "cxyz"), (64, "czyx"), (40, "cxyz")):
+        got = pkg.voxelize_aug(td, to, th, txf, res=R, layout=layout)
+        torch.cuda.synchronize()
+        with np.errstate(all="ignore"):
+            ref = oracle.voxelize_aug(depth, off, hdr, xf, R=R, layout=0 if layout == "czyx" else 1, n_threads=8)
+        np.testing.assert_array_equal(got.status.cpu().numpy(), ref["status"])
+        np.testing.assert_array_equal(got.max_l.cpu().numpy(), ref["max_l"])
+        g = got.tsdf.cpu().numpy()
+        assert np.isfinite(g).all() and np.isfinite(ref["tsdf"]).all()
+        err = np.abs(g - ref["tsdf"]).reshape(n, -1).max(axis=1)
+        assert err.max() <= TOL, (R, layout, err)
+        assert np.abs(g[0]).max() > 0 and np.abs(g[6]).max() > 0
