@@ -1939,6 +1939,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(box + kExt, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      TSDF_STAMP(0, 13);
       // ---- collect the siblings' (wave 0: lane q watches mailbox q), bounded ----
       if (wave == 0) {
         const int lane = tid & 63;
@@ -1979,6 +1980,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
         for (int i = 0; i < kExt; ++i) fin[i] = __uint_as_float(pg.rowtab[i]);
       }
     }
+    TSDF_STAMP(0, 12);
     if (!have) {
       // the redundant form: this workgroup streams the whole frame (and captures the valid row windows)
       cap.on = !XCHG && want_vol && f.bw <= kMaxCapW && f.bh <= kMaxRows;

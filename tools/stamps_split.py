@@ -31,3 +31,7 @@ for kind in ("full", "crop"):
         m = np.median(r, axis=0)
         print(f"{kind} n={n}: {s.shape[0]} workgroups; medians (us) start {m[0]:.2f}  rows streamed {m[1]:.2f}  partials in LDS {m[2]:.2f}  "
               f"extents known {m[3]:.2f}  staged+tables {m[4]:.2f}  voxels issued {m[5]:.2f}  stores done {m[6]:.2f}  (max end {r[:,6].max():.2f})")
+        if os.environ.get("STAMPS_ROWS"):   # every workgroup of the first frame: who waits for whom in the exchange
+            np.set_printoptions(precision=2, suppress=True, linewidth=160)
+            print(r[: s.shape[0] // n])
+            print('published / exchange done:', ((s[: s.shape[0] // n][:, [13, 12]] - t0) / 100.0).tolist())
