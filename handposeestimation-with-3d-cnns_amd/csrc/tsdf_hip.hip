@@ -1398,10 +1398,8 @@ __device__ __forceinline__ void write_labels(const KArgs &a, int frame, const Gr
     const int c = e % 3;
     const float *gj = a.gt + (int64_t)frame * nc + (e - c);
     float v = gj[c];
-    if (xf) {
-      v = (float)affine_row(xf + 4 * c, (double)gj[0], (double)gj[1], (double)gj[2]);
-      if (a.gt_aug) a.gt_aug[(int64_t)frame * nc + e] = v;
-    }
+    if (xf) v = (float)affine_row(xf + 4 * c, (double)gj[0], (double)gj[1], (double)gj[2]);
+    if (a.gt_aug) a.gt_aug[(int64_t)frame * nc + e] = v;  // the joints in the grid's frame (plain path: a copy)
     float o = 0.5f;
     if (status == TSDF_FRAME_OK) {
       const float m = c == 0 ? g.mid[0] : (c == 1 ? g.mid[1] : g.mid[2]);
@@ -2333,7 +2331,7 @@ int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const
   if (o.labels) {
     a.gt = o.labels->d_gt;
     a.gt_nor = o.labels->d_out_gt_nor;
-    a.gt_aug = o.xforms ? o.labels->d_out_gt_aug : nullptr;
+    a.gt_aug = o.labels->d_out_gt_aug;
     a.n_joints = o.labels->n_joints;
     a.clamp = o.labels->clamp;
   }

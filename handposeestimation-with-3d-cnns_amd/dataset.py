@@ -252,9 +252,9 @@ class _Staging:
         self.h_hdr = torch.empty((bs, 6), dtype=torch.int32).pin_memory()
         self.h_gt = torch.empty((bs, 63), dtype=torch.float32).pin_memory() if with_gt else None
         self.d_depth = torch.empty(max_px, dtype=torch.float32, device=device)
-        self.d_off = torch.empty(bs + 1, dtype=torch.int64, device=device)
-        self.d_hdr = torch.empty((bs, 6), dtype=torch.int32, device=device)
-        self.d_gt = torch.empty((bs, 63), dtype=torch.float32, device=device) if with_gt else None
+        # offsets / headers / labels stay in the pinned buffers: the voxelizer reads them over the link (include/tsdf.h).
+        # ONE copy per batch: a small copy between two big ones can halve the next big one's rate (the runtime's
+        # choice of copy engine; tools/exp_loader_meta.py: 630 k vs 880 k crops/s with the same bytes).
         self.copied = torch.cuda.Event()
         self.consumed = torch.cuda.Event()
         self.filled = threading.Event()   # host side: the worker has packed a batch into the pinned buffers
@@ -307,8 +307,7 @@ class VoxelLoader:
         sets = self._sets
         for s in sets:
             if s.used:
-                s.copied.synchronize()   # an abandoned previous epoch may still be uploading from this set
-                s.consumed.synchronize()
+                s.consumed.synchronize()   # an abandoned previous epoch may still be reading this set
             s.free.set()
             s.filled.clear()
             s.used = False
@@ -324,7 +323,8 @@ class VoxelLoader:
                             return
                     s.free.clear()
                     if s.used:
-                        s.copied.synchronize()   # the previous upload out of this set's pinned buffers is done
+                        s.consumed.synchronize()   # the kernel that read this set's pinned metadata (and therefore
+                                                   # the upload out of its pinned depth buffer) is done
                     direct = self.ds.contiguous_source(b)
                     if direct is not None:            # DMA straight out of the pinned pack: no staging copy
                         s.src, pk = direct
@@ -361,20 +361,16 @@ class VoxelLoader:
                     if k >= 2:
                         copy_stream.wait_event(s.consumed)   # the kernels that read this device set are done
                     s.d_depth[:npx].copy_(s.src, non_blocking=True)
-                    s.d_off[: n + 1].copy_(s.h_off[: n + 1], non_blocking=True)
-                    s.d_hdr[:n].copy_(s.h_hdr[:n], non_blocking=True)
-                    s.d_gt[:n].copy_(s.h_gt[:n], non_blocking=True)
                     s.copied.record(copy_stream)
                 cur.wait_event(s.copied)
-                depth, off, hdr = s.d_depth[:npx], s.d_off[: n + 1], s.d_hdr[:n]
-                gt = s.d_gt[:n].clone()   # the yielded labels outlive the staging set
-                if self.labels:
-                    out, gt_nor = voxelize_labels(depth, off, hdr, gt, res=self.res, layout=self.layout, clamp=self.clamp)
-                else:
-                    out, gt_nor = voxelize(depth, off, hdr, res=self.res, layout=self.layout), None
+                # one launch: volumes, max_l / mid_p, normalised labels and the labels' device copy (which outlives the set)
+                out, gt_nor, gt = voxelize_labels(s.d_depth[:npx], s.h_off[: n + 1], s.h_hdr[:n], s.h_gt[:n], res=self.res,
+                                                  layout=self.layout, clamp=self.clamp, gt_copy=True)
+                if not self.labels:
+                    gt_nor = None
                 s.consumed.record(cur)
                 s.used = True
-                s.free.set()   # the copy is issued: the worker may reuse the pinned buffers once `copied` has fired
+                s.free.set()   # issued: the worker may reuse the pinned buffers once `consumed` has fired
                 yield VoxelBatch(out.tsdf, gt, out.max_l, out.mid_p, out.status, gt_nor)
         finally:
             stop.set()

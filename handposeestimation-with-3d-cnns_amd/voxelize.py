@@ -23,11 +23,16 @@ class TsdfBatch(NamedTuple):
     status: torch.Tensor  # int32[n]  (_lib.TSDF_FRAME_*)
 
 
-def _dev_check(name, t, dtype, device=None):
+def _dev_check(name, t, dtype, device=None, host_ok=False):
+    """``host_ok``: the per-frame metadata (offsets, headers, gt) may also be PAGE-LOCKED host memory, which the
+    GPU reads over the link (include/tsdf.h) — a pinned CPU tensor then passes; pageable memory never does."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
-    if not t.is_cuda:
-        raise ValueError(f"{name} must live on the GPU (there is no CPU path); got device {t.device}")
+    if host_ok and not t.is_cuda and t.is_pinned():
+        device = None
+    elif not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU" + (" or in page-locked host memory" if host_ok else "") +
+                         f" (there is no CPU path); got device {t.device}")
     if t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -42,8 +47,8 @@ def _check_inputs(L, depth, offsets, headers, res, layout):
         raise ValueError("layout must be 'czyx' or 'cxyz'")
     _dev_check("depth", depth, torch.float32)
     dev = depth.device
-    _dev_check("offsets", offsets, torch.int64, dev)
-    _dev_check("headers", headers, torch.int32, dev)
+    _dev_check("offsets", offsets, torch.int64, dev, host_ok=True)
+    _dev_check("headers", headers, torch.int32, dev, host_ok=True)
     if headers.dim() != 2 or headers.shape[1] != 6:
         raise ValueError("headers must have shape [n, 6]")
     n = headers.shape[0]
@@ -76,19 +81,19 @@ def _make_out(out, n, R, dev) -> "TsdfBatch":
 
 def _labels_struct(gt, n, dev, clamp, out_gt_nor=None, want_aug=False):
     """Validate the label tensors and build the ``tsdf_labels`` struct (kept alive by the caller)."""
-    _dev_check("gt", gt, torch.float32, dev)
+    _dev_check("gt", gt, torch.float32, dev, host_ok=True)
     if gt.shape[0] != n or gt.numel() % (3 * max(n, 1)) != 0 and n > 0:
         raise ValueError("gt must have shape [n, 3*J] or [n, J, 3]")
     nc = gt.numel() // n if n else 63
     if nc % 3 or not 1 <= nc // 3 <= 170:
         raise ValueError("gt must hold 1..170 joints of 3 coordinates per frame")
     if out_gt_nor is None:
-        out_gt_nor = torch.empty_like(gt)
+        out_gt_nor = torch.empty(gt.shape, dtype=torch.float32, device=dev)
     else:
         _dev_check("out_gt_nor", out_gt_nor, torch.float32, dev)
         if out_gt_nor.shape != gt.shape:
             raise ValueError("out_gt_nor must have gt's shape")
-    gt_aug = torch.empty_like(gt) if want_aug else None
+    gt_aug = torch.empty(gt.shape, dtype=torch.float32, device=dev) if want_aug else None
     lab = _lib.TsdfLabels(gt.data_ptr(), nc // 3, 1 if clamp else 0, out_gt_nor.data_ptr(),
                           gt_aug.data_ptr() if gt_aug is not None else None)
     return lab, out_gt_nor, gt_aug
@@ -125,17 +130,22 @@ def voxelize(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, 
 
 def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, gt: torch.Tensor,
                     res: int = 32, layout: str = "czyx", cam: Optional[_lib.TsdfCam] = None, clamp: bool = True,
-                    out: Optional[TsdfBatch] = None, out_gt_nor: Optional[torch.Tensor] = None):
+                    out: Optional[TsdfBatch] = None, out_gt_nor: Optional[torch.Tensor] = None,
+                    gt_copy: bool = False):
     """:func:`voxelize` plus the label normalisation of the same launch: ``(gt - mid_p) / max_l + 0.5`` per
     joint coordinate (pre/joint_nor.py:8-18), clamped to [0,1] as 3D_CNN/train.py:241-242 does (``clamp``).
     gt float32[n,63] (or [n,J,3]) on the GPU.  Returns ``(TsdfBatch, gt_nor)``; frames whose status is not 0
-    get 0.5 everywhere."""
+    get 0.5 everywhere.
+
+    ``offsets``, ``headers`` and ``gt`` may be pinned CPU tensors (read by the kernel over the link; they must not
+    change before the launch has finished); ``gt_copy=True`` then also returns the joints as a device tensor,
+    written by the same launch: ``(TsdfBatch, gt_nor, gt_on_device)``."""
     L = _lib.load()
     dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
     out = _make_out(out, n, R, dev)
-    lab, gt_nor, _ = _labels_struct(gt, n, dev, clamp, out_gt_nor)
+    lab, gt_nor, gt_dev = _labels_struct(gt, n, dev, clamp, out_gt_nor, want_aug=gt_copy)
     if n == 0:
-        return out, gt_nor
+        return (out, gt_nor, gt_dev) if gt_copy else (out, gt_nor)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = L.tsdf_voxelize_labels_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
@@ -143,7 +153,7 @@ def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.T
                                         out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(),
                                         out.status.data_ptr(), ctypes.byref(lab))
     _lib.check(rc, "tsdf_voxelize_labels_hip")
-    return out, gt_nor
+    return (out, gt_nor, gt_dev) if gt_copy else (out, gt_nor)
 
 
 def normalize_joints(gt: torch.Tensor, max_l: torch.Tensor, mid_p: torch.Tensor, clamp: bool = True,
@@ -236,8 +246,8 @@ def aabb(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res:
     L = _lib.load()
     _dev_check("depth", depth, torch.float32)
     dev = depth.device
-    _dev_check("offsets", offsets, torch.int64, dev)
-    _dev_check("headers", headers, torch.int32, dev)
+    _dev_check("offsets", offsets, torch.int64, dev, host_ok=True)
+    _dev_check("headers", headers, torch.int32, dev, host_ok=True)
     if headers.dim() != 2 or headers.shape[1] != 6:
         raise ValueError("headers must have shape [n, 6]")
     n = headers.shape[0]

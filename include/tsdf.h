@@ -114,6 +114,13 @@ int tsdf_resolution_supported(int R);
  *                                   not lie inside it is treated as TSDF_FRAME_BAD_HEADER and never read.
  *   d_offsets  int64[n+1]           element offsets into d_depth, non-decreasing.
  *   d_headers  int32[n][6]          W, H, left, top, right, bottom (the .bin header).
+ *                                   d_offsets, d_headers and tsdf_labels.d_gt — the per-frame metadata, 32..300 bytes
+ *                                   a frame, each word read once — may also be DEVICE-ACCESSIBLE PAGE-LOCKED HOST
+ *                                   memory (hipHostMalloc): the kernel then fetches them over the link, which costs
+ *                                   a few us per launch and saves the caller three small copies per batch (a
+ *                                   streaming loader's depth upload keeps the link's rate only when no small copy
+ *                                   sits between two big ones: tools/exp_loader_meta.py).  The memory must stay
+ *                                   unchanged until the launch has finished.  Everything else is device memory.
  *   n          number of frames (0 is allowed and is a no-op).
  *   R          grid resolution (reference: 32).
  *   cam        constants, or NULL for the MSRA defaults.
@@ -209,9 +216,11 @@ typedef struct tsdf_labels {
   int n_joints;        /* 21 for MSRA; 1..170                                                               */
   int clamp;           /* 1: clamp to [0,1] (3D_CNN/train.py:241-242); 0: pre/joint_nor.py as written       */
   float *d_out_gt_nor; /* float32[n][3*n_joints]                                                            */
-  float *d_out_gt_aug; /* tsdf_voxelize_aug_labels_hip only, may be NULL: T(joint) in mm (the joints mapped
-                          with the frame's forward map, as pre/process.py:232-249 maps them with the cloud's
-                          S and R); the normalised labels are then those of T(joint) in the augmented grid   */
+  float *d_out_gt_aug; /* may be NULL: T(joint) in mm — the joints in the frame of the grid.  With
+                          tsdf_voxelize_aug_labels_hip they are mapped with the frame's forward map (as
+                          pre/process.py:232-249 maps them with the cloud's S and R) and the normalised labels
+                          are those of T(joint) in the augmented grid; with tsdf_voxelize_labels_hip T is the
+                          identity, i.e. this is a device copy of d_gt (for callers whose d_gt is host memory) */
 } tsdf_labels;
 
 /* tsdf_voxelize_hip + labels.  `labels` is a HOST struct of device pointers, read during the call. */

@@ -166,6 +166,36 @@ int main(void) {
     for (int i = 0; i < N; ++i)
       for (int j = 0; j < 3 * J; ++j) werr = fmax(werr, fabs((double)got_back[i][j] - gt[i][j]));
     check(werr < 2e-3, "  denormalize(normalize(gt)) == gt to float32 rounding");
+    /* offsets / headers / gt in page-locked host memory (hipHostMalloc), read by the kernel over the link; the plain
+     * label entry's d_out_gt_aug is then the joints' device copy */
+    {
+      int64_t *h_off;
+      int32_t *h_hdr;
+      float *h_gt, *d_copy;
+      static float got_copy[N][3 * J], got_nor2[N][3 * J];
+      HIP(hipHostMalloc((void **)&h_off, sizeof offsets, hipHostMallocDefault));
+      HIP(hipHostMalloc((void **)&h_hdr, sizeof headers, hipHostMallocDefault));
+      HIP(hipHostMalloc((void **)&h_gt, sizeof gt, hipHostMallocDefault));
+      HIP(hipMalloc((void **)&d_copy, sizeof gt));
+      memcpy(h_off, offsets, sizeof offsets);
+      memcpy(h_hdr, headers, sizeof headers);
+      memcpy(h_gt, gt, sizeof gt);
+      HIP(hipMemsetAsync(d_nor, 0, sizeof gt, stream));
+      tsdf_labels hl = {h_gt, J, 1, d_nor, d_copy};
+      check(tsdf_voxelize_labels_hip(d_depth, total, h_off, h_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s, &hl) == TSDF_OK,
+            "metadata in page-locked host memory: TSDF_OK");
+      HIP(hipMemcpyAsync(got_nor2, d_nor, sizeof gt, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(got_copy, d_copy, sizeof gt, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(got_l, d_l, sizeof got_l, hipMemcpyDeviceToHost, stream));
+      HIP(hipStreamSynchronize(stream));
+      check(memcmp(got_nor2, ref_nor, sizeof gt) == 0 && memcmp(got_l, ref_l, sizeof got_l) == 0,
+            "  labels and max_l bit exact");
+      check(memcmp(got_copy, gt, sizeof gt) == 0, "  d_out_gt_aug of the plain entry: the joints' device copy");
+      HIP(hipHostFree(h_off));
+      HIP(hipHostFree(h_hdr));
+      HIP(hipHostFree(h_gt));
+      HIP(hipFree(d_copy));
+    }
     lab.n_joints = 0;
     check(tsdf_voxelize_labels_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s, &lab) ==
               TSDF_ERR_INVALID_ARG, "n_joints = 0 -> TSDF_ERR_INVALID_ARG");

@@ -1033,3 +1033,33 @@ def test_augmented_projection_division_forms(pkg, synth):
         err = np.abs(g - ref["tsdf"]).reshape(n, -1).max(axis=1)
         assert err.max() <= TOL, (R, layout, err)
         assert np.abs(g[0]).max() > 0 and np.abs(g[6]).max() > 0
+
+
+def test_metadata_in_page_locked_host_memory(pkg, synth):
+    """offsets / headers / gt may be device-accessible page-locked host memory (include/tsdf.h): the kernels read them
+    over the link.  Same results bit for bit as from device memory, on the fused kernel (n = 300), the split kernel
+    (n = 5) and the augmented entry; the plain label entry's device copy of gt; pageable host memory is refused."""
+    d = dev()
+    for n in (300, 5):
+        depth, off, hdr = synth.synth_batch(n, "crop", seed0=4100)
+        gt = np.random.default_rng(n).normal(0, 80, (n, 63)).astype(np.float32)
+        td, to, th, tg = (torch.from_numpy(a).to(d) for a in (depth, off, hdr, gt))
+        po, ph, pg = (torch.from_numpy(a).pin_memory() for a in (off, hdr, gt))
+        want, want_nor = pkg.voxelize_labels(td, to, th, tg)
+        got, got_nor, got_gt = pkg.voxelize_labels(td, po, ph, pg, gt_copy=True)
+        torch.cuda.synchronize()
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        assert torch.equal(want_nor, got_nor) and got_gt.is_cuda and torch.equal(got_gt.cpu(), pg)
+        assert torch.equal(pkg.voxelize(td, po, ph).tsdf, want.tsdf)
+        for a, b in zip(pkg.aabb(td, po, ph), pkg.aabb(td, to, th)):
+            assert torch.equal(a, b)
+        xf = torch.from_numpy(pkg.augment.random_affines(want.mid_p.cpu().numpy(), rng=3)[0]).to(d)
+        a1 = pkg.voxelize_aug(td, to, th, xf, gt=tg)
+        a2 = pkg.voxelize_aug(td, po, ph, xf, gt=pg)
+        torch.cuda.synchronize()
+        assert torch.equal(a1[0].tsdf, a2[0].tsdf) and torch.equal(a1[1], a2[1]) and torch.equal(a1[2], a2[2])
+    with pytest.raises(ValueError):
+        pkg.voxelize(td, torch.from_numpy(off), th)          # pageable host memory: no
+    with pytest.raises(ValueError):
+        pkg.voxelize(torch.from_numpy(depth).pin_memory(), to, th)   # the depth payload itself must be on the device

@@ -15,6 +15,8 @@ lens = np.tile(np.diff(base.offsets), reps)[:n]
 off = np.zeros(n + 1, np.int64); np.cumsum(lens, out=off[1:])
 pk = pkg.packing.PackedFrames(np.ascontiguousarray(np.tile(base.depth, reps)[: off[-1]]), off,
                               np.ascontiguousarray(np.tile(base.headers, (reps, 1))[:n]), np.zeros((n, 63), np.float32))
+if os.environ.get("BIG_FIRST") == "1":   # the context bench.py's extras run in: 30 GB went through the allocator before
+    big = torch.empty(30 * 1024**3 // 4, device=dev); del big; torch.cuda.empty_cache()
 loader = pkg.VoxelLoader(pkg.MSRADepthDataset.from_packs([pk]), batch_size=1024, device=dev, max_pixels=1024 * 160 * 160)
 for ep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter(); seen = 0
