@@ -234,7 +234,8 @@ def extras(pkg, synth, dev, td, to, th, offsets):
         "h2d_GBps": round(in_bytes * max(rates[2:]) / 8500 / 1e9, 2),
         "epochs_crops_per_s": [round(r) for r in rates],
         "what": "BASELINE configs[2]: 8,500 MSRA-like crops from a page-locked pack through dataset.VoxelLoader "
-                "(hipMemcpyAsync on a copy stream overlapped with the fused voxelizer + labels); PCIe-bound"}
+                "(ONE hipMemcpyAsync per batch on a copy stream, overlapped with the fused voxelizer + labels, which reads "
+                "offsets / headers / labels from page-locked host memory); PCIe-bound"}
     # the same pipeline over four subjects' worth of frames: the 8,500-frame number above carries the fixed cost of
     # starting and draining a 9-batch epoch
     del loader, ds
