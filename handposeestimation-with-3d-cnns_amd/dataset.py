@@ -388,7 +388,12 @@ class MSRA_Dataset(data.Dataset):
     reference returns numpy rows that its training loop then moves with ``.cuda()``, train.py:200,232).
     ``opt.size`` / ``opt.test_index`` are honoured when present (the reference ignores ``opt`` and hard-codes
     ``'small'`` / 2, :20-22); ``aug=True`` is rejected like ``DataProcess(aug=True)``: use ``voxelize_aug``.
-    For training throughput use :class:`VoxelLoader`, which overlaps reading, upload and voxelization.
+
+    Under the reference's own ``DataLoader(dataset, batch_size=B, shuffle=True)`` (train.py:137-141; ``num_workers=0``:
+    the items are GPU tensors) the loader hands the batch's indices to :meth:`__getitems__`, which voxelizes exactly
+    those B frames in ONE launch; a lone ``dataset[i]`` voxelizes frame i alone unless the access pattern is a sequential
+    walk, which is served from a block.  For training throughput use :class:`VoxelLoader`, which overlaps reading,
+    upload and voxelization.
     """
 
     def __init__(self, root_path, opt=None, train=True, aug=False, device="cuda", block: int = 1024,
@@ -407,6 +412,7 @@ class MSRA_Dataset(data.Dataset):
         self._cache_block = -1
         self._cache: Optional[TsdfBatch] = None
         self._cache_gt: Optional[torch.Tensor] = None
+        self._last = -1          # the last index served (a sequential walk is answered from blocks)
 
     def __len__(self):
         return len(self.raw)
@@ -419,13 +425,29 @@ class MSRA_Dataset(data.Dataset):
         self._cache_gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
         self._cache_block = blk
 
+    def __getitems__(self, indices):
+        """The frames of one batch, voxelized by one launch (torch's DataLoader calls this with the batch's indices
+        when it exists): a list of item tuples, views into the batch's tensors."""
+        idx = np.asarray([int(i) for i in indices], np.int64)
+        if idx.size and (idx.min() < 0 or idx.max() >= len(self.raw)):
+            raise IndexError(int(idx.max() if idx.max() >= len(self.raw) else idx.min()))
+        self._last = int(idx[-1]) if idx.size else self._last
+        pk = self.raw.take(idx)
+        depth, offsets, headers = pk.to_torch(self.device, pin=False, non_blocking=False)
+        out = voxelize(depth, offsets, headers, res=32)
+        gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
+        return [(out.tsdf[k], gt[k], out.max_l[k], out.mid_p[k]) for k in range(idx.size)]
+
     def __getitem__(self, index):
         index = int(index)
         if not 0 <= index < len(self.raw):
             raise IndexError(index)
         blk = index // self.block
         if blk != self._cache_block:
-            self._load_block(blk)
+            if index != self._last + 1 and index % self.block:   # random access: this frame alone
+                return self.__getitems__([index])[0]
+            self._load_block(blk)                                 # a sequential walk: the whole block at once
+        self._last = index
         k = index - blk * self.block
         c = self._cache
         return c.tsdf[k], self._cache_gt[k], c.max_l[k], c.mid_p[k]

@@ -381,6 +381,29 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
         tsdf, gt, max_l, mid_p = rds[i]
         assert tsdf.shape == (3, 32, 32, 32) and gt.shape == (63,)
         assert np.abs(tsdf.cpu().numpy() - ref["tsdf"][i]).max() <= TOL and float(max_l) == ref["max_l"][i]
+    # the reference's own loader call (3D_CNN/train.py:86-88: DataLoader(dataset, batch_size, shuffle=True)): torch hands
+    # each batch's indices to __getitems__ -> ONE launch per batch, no block of 1024 frames voxelized for one item
+    blocks = []
+    rds._load_block = lambda blk, _f=rds._load_block: (blocks.append(blk), _f(blk))[1]
+    rds._cache_block = -1
+    g = torch.Generator().manual_seed(5)
+    seen = []
+    for tsdf, gt, max_l, mid_p in torch.utils.data.DataLoader(rds, batch_size=3, shuffle=True, num_workers=0, generator=g):
+        assert tsdf.is_cuda and tsdf.shape[1:] == (3, 32, 32, 32) and gt.shape[1] == 63
+        for k in range(tsdf.shape[0]):
+            i = int(np.flatnonzero(ref["max_l"] == float(max_l[k]))[0])
+            assert np.abs(tsdf[k].cpu().numpy() - ref["tsdf"][i]).max() <= TOL
+            np.testing.assert_array_equal(mid_p[k].cpu().numpy(), ref["mid_p"][i])
+            seen.append(i)
+    assert sorted(seen) == list(range(8)) and blocks == []
+    # lone random accesses voxelize one frame; a sequential walk is served from blocks
+    rds._last = 100   # (whatever the shuffled epoch ended on must not make index 6 look like the next of a walk)
+    for i in (6, 1, 3):
+        assert float(rds[i][2]) == ref["max_l"][i]
+    assert blocks == []
+    for i in range(8):
+        assert float(rds[i][2]) == ref["max_l"][i]
+    assert blocks == [0, 1]
     with pytest.raises(NotImplementedError):
         pkg.MSRA_Dataset(str(tmp_path), Opt(), aug=True)
 
