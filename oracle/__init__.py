@@ -121,7 +121,14 @@ def voxels(depth, header, ori, voxel_len, trunc_dis, R=32, layout=0, want_pixmap
     return (out, pm) if want_pixmap else out
 
 
-def voxelize(depth, offsets, headers, R=32, layout=0, n_threads=1, want_tsdf=True, extras=False):
+def _cam(cam):
+    """None, a TsdfCam, or (focal, cx, cy, invalid_eps, trunc_voxels) -> argument for the C entry points."""
+    if cam is None or isinstance(cam, TsdfCam):
+        return ctypes.byref(cam) if cam is not None else None
+    return ctypes.byref(TsdfCam(*[float(v) for v in cam]))
+
+
+def voxelize(depth, offsets, headers, R=32, layout=0, n_threads=1, want_tsdf=True, extras=False, cam=None):
     """Batch form, same argument meaning as ``tsdf_voxelize_hip`` but on host arrays.
 
     Returns dict(tsdf, max_l, mid_p, status[, aabb, grid, ori], threads).
@@ -139,7 +146,7 @@ def voxelize(depth, offsets, headers, R=32, layout=0, n_threads=1, want_tsdf=Tru
     ori = np.empty((n, 3), np.float32) if extras else None
     used = lib().tsdf_oracle_voxelize(
         _p(depth, ctypes.c_float), _p(offsets, ctypes.c_int64), _p(headers, ctypes.c_int32), n, R,
-        None, layout, n_threads, _p(out, ctypes.c_float), _p(max_l, ctypes.c_float),
+        _cam(cam), layout, n_threads, _p(out, ctypes.c_float), _p(max_l, ctypes.c_float),
         _p(mid_p, ctypes.c_float), _p(status, ctypes.c_int32), _p(ab, ctypes.c_float),
         _p(grid, ctypes.c_float), _p(ori, ctypes.c_float))
     res = dict(tsdf=out, max_l=max_l, mid_p=mid_p, status=status, threads=int(used))
@@ -148,7 +155,7 @@ def voxelize(depth, offsets, headers, R=32, layout=0, n_threads=1, want_tsdf=Tru
     return res
 
 
-def voxelize_aug(depth, offsets, headers, xforms, R=32, layout=0, n_threads=1):
+def voxelize_aug(depth, offsets, headers, xforms, R=32, layout=0, n_threads=1, cam=None):
     """Augmented form (re-specified, parity unpinned; see tsdf_oracle.c): xforms float64[n,24] =
     forward affine rows {A_i0,A_i1,A_i2,b_i} then the inverse.  Returns dict(tsdf,max_l,mid_p,status)."""
     depth = np.ascontiguousarray(depth, dtype=np.float32)
@@ -162,7 +169,7 @@ def voxelize_aug(depth, offsets, headers, xforms, R=32, layout=0, n_threads=1):
     mid_p = np.empty((n, 3), np.float32)
     status = np.empty(n, np.int32)
     lib().tsdf_oracle_voxelize_aug(
-        _p(depth, ctypes.c_float), _p(offsets, ctypes.c_int64), _p(headers, ctypes.c_int32), n, R, None,
+        _p(depth, ctypes.c_float), _p(offsets, ctypes.c_int64), _p(headers, ctypes.c_int32), n, R, _cam(cam),
         layout, n_threads, _p(xforms, ctypes.c_double), _p(out, ctypes.c_float), _p(max_l, ctypes.c_float),
         _p(mid_p, ctypes.c_float), _p(status, ctypes.c_int32))
     return dict(tsdf=out, max_l=max_l, mid_p=mid_p, status=status)

@@ -1086,3 +1086,33 @@ def test_metadata_in_page_locked_host_memory(pkg, synth):
         pkg.voxelize(td, torch.from_numpy(off), th)          # pageable host memory: no
     with pytest.raises(ValueError):
         pkg.voxelize(torch.from_numpy(depth).pin_memory(), to, th)   # the depth payload itself must be on the device
+
+
+@pytest.mark.parametrize("camv", [(300.0, 150.5, 118.25, 2.0, 2.5), (588.03, 320.0, 240.0, 1.0, 3.0),
+                                  (120.7, 80.0, 60.0, 0.5, 1.0), (241.42, 160.0, 120.0, 250.0, 8.0)])
+def test_custom_camera_constants(pkg, synth, camv):
+    """tsdf_cam other than the MSRA defaults (focal length, principal point, the invalid-depth threshold of
+    tsdf_numba.py:40,87 and the truncation distance in voxels of :147): every entry point against the oracle given the
+    same constants — the kernel's reciprocal of the focal length, its folded pixel constants and its truncation
+    reciprocal all derive from them."""
+    d = dev()
+    cam_o = camv
+    cam_h = pkg.TsdfCam(*camv)
+    for n, kind in ((150, "crop"), (9, "full")):
+        depth, off, hdr = synth.synth_batch(n, kind, seed0=5200)
+        td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+        for R, layout in ((32, "czyx"), (40, "cxyz")):
+            got = pkg.voxelize(td, to, th, res=R, layout=layout, cam=cam_h)
+            torch.cuda.synchronize()
+            ref = oracle.voxelize(depth, off, hdr, R=R, layout=0 if layout == "czyx" else 1, n_threads=8, cam=cam_o)
+            np.testing.assert_array_equal(got.status.cpu().numpy(), ref["status"])
+            np.testing.assert_array_equal(got.max_l.cpu().numpy(), ref["max_l"])
+            np.testing.assert_array_equal(got.mid_p.cpu().numpy(), ref["mid_p"])
+            assert np.abs(got.tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+        assert (ref["status"] == 0).any()
+        xf = pkg.augment.random_affines(ref["mid_p"], rng=4)[0]
+        ga = pkg.voxelize_aug(td, to, th, torch.from_numpy(xf).to(d), res=32, cam=cam_h)
+        torch.cuda.synchronize()
+        ra = oracle.voxelize_aug(depth, off, hdr, xf, R=32, n_threads=8, cam=cam_o)
+        np.testing.assert_array_equal(ga.max_l.cpu().numpy(), ra["max_l"])
+        assert np.abs(ga.tsdf.cpu().numpy() - ra["tsdf"]).max() <= TOL
