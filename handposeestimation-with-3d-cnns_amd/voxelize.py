@@ -23,9 +23,41 @@ class TsdfBatch(NamedTuple):
     status: torch.Tensor  # int32[n]  (_lib.TSDF_FRAME_*)
 
 
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_stream(dev) -> int:
+    """hipStream_t of torch's current stream on ``dev`` as an integer (without building a torch Stream object: at
+    batch 16 the host side of a call is longer than the kernel, tools/exp_latency_parts.py)."""
+    if _get_raw_stream is not None:
+        return _get_raw_stream(dev.index)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _Current:
+    """``with _current(dev):`` — makes ``dev`` the current device, at no cost when it already is."""
+
+    __slots__ = ("guard",)
+
+    def __init__(self, dev):
+        self.guard = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
 def _dev_check(name, t, dtype, device=None, host_ok=False):
     """``host_ok``: the per-frame metadata (offsets, headers, gt) may also be PAGE-LOCKED host memory, which the
     GPU reads over the link (include/tsdf.h) — a pinned CPU tensor then passes; pageable memory never does."""
+    if t.__class__ is torch.Tensor and t.is_cuda and t.dtype is dtype and t.is_contiguous() and \
+            (device is None or t.device == device):
+        return   # the common case, in one expression: this runs seven times per call
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if host_ok and not t.is_cuda and t.is_pinned():
@@ -118,8 +150,8 @@ def voxelize(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, 
     out = _make_out(out, n, R, dev)
     if n == 0:
         return out
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev).cuda_stream
+    with _Current(dev):
+        stream = _raw_stream(dev)
         rc = L.tsdf_voxelize_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                  ctypes.byref(cam) if cam is not None else None,
                                  _lib.LAYOUTS[layout], stream, out.tsdf.data_ptr(),
@@ -146,8 +178,8 @@ def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.T
     lab, gt_nor, gt_dev = _labels_struct(gt, n, dev, clamp, out_gt_nor, want_aug=gt_copy)
     if n == 0:
         return (out, gt_nor, gt_dev) if gt_copy else (out, gt_nor)
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev).cuda_stream
+    with _Current(dev):
+        stream = _raw_stream(dev)
         rc = L.tsdf_voxelize_labels_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                         ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], stream,
                                         out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(),
@@ -190,8 +222,8 @@ def _norm_call(x, max_l, mid_p, clamp, inverse, out):
         if out.shape != x.shape:
             raise ValueError("out must have the input's shape")
     if n:
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _Current(dev):
+            stream = _raw_stream(dev)
             if inverse:
                 rc = L.tsdf_denormalize_joints_hip(x.data_ptr(), max_l.data_ptr(), mid_p.data_ptr(), n, nc // 3,
                                                    stream, out.data_ptr())
@@ -223,8 +255,8 @@ def voxel_pixels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tens
     pm = torch.empty((n, R, R, R), dtype=torch.int32, device=dev)
     st = torch.empty((n,), dtype=torch.int32, device=dev)
     if n:
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _Current(dev):
+            stream = _raw_stream(dev)
             rc = L.tsdf_debug_pixmap_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                          ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], stream,
                                          grid.data_ptr() if grid is not None else None, tsdf.data_ptr(),
@@ -260,8 +292,8 @@ def aabb(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res:
     ori = torch.empty((n, 3), dtype=torch.float32, device=dev)
     st = torch.empty((n,), dtype=torch.int32, device=dev)
     if n:
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _Current(dev):
+            stream = _raw_stream(dev)
             rc = L.tsdf_aabb_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, int(res),
                                  ctypes.byref(cam) if cam is not None else None, stream,
                                  ab.data_ptr(), grid.data_ptr(), ori.data_ptr(), st.data_ptr())
@@ -285,8 +317,8 @@ def voxelize_grid(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Ten
     tsdf = torch.empty((n, 3, R, R, R), dtype=torch.float32, device=dev)
     st = torch.empty((n,), dtype=torch.int32, device=dev)
     if n:
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _Current(dev):
+            stream = _raw_stream(dev)
             rc = L.tsdf_voxelize_grid_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                                           ctypes.byref(cam) if cam is not None else None,
                                           _lib.LAYOUTS[layout], stream, grid.data_ptr(), tsdf.data_ptr(),
@@ -318,8 +350,8 @@ def voxelize_aug(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tens
     if gt is not None:
         lab, gt_nor, gt_aug = _labels_struct(gt, n, dev, clamp, want_aug=True)
     if n:
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _Current(dev):
+            stream = _raw_stream(dev)
             args = (depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n, R,
                     ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], stream, xforms.data_ptr(),
                     out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr())
