@@ -150,6 +150,37 @@ def _time_launches(fn, k, warm=3):
     return a.elapsed_time(b) / k * 1e3
 
 
+def stream_ceilings():
+    """What plain stream kernels reach on THIS box (tools/probes/hbm_probe.hip, built by __graft_entry__.build(); a child
+    process, ~2 s): read-only, write-only, copy and the voxelizer's 307:393 read:write mix, best grid of four.  Context
+    for roofline.frac — the spec peak is not what a stream gets, and reads and writes differ.  None if not built."""
+    exe = os.path.join(ROOT, "tools", "probes", "hbm_probe.bin")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    try:
+        txt = subprocess.run([exe, "384"], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    import re
+    best = {}
+    for line in txt.splitlines():
+        m = re.match(r"grid\s+\d+ x1024\s+(.*?)\s+[\d.]+ us\s+([\d.]+) GB/s", line)
+        if m:
+            best[m.group(1)] = max(best.get(m.group(1), 0.0), float(m.group(2)))
+    keys = {"read": "read_only", "write nt": "write_only_nt", "copy": "copy", "copy nt": "copy_nt",
+            "same, nt stores": "read_then_write_307_393_nt", "read then write 307:393": "read_then_write_307_393"}
+    res = {v: best[k] for k, v in keys.items() if k in best}
+    if not res:
+        return None
+    res["unit"] = "GB/s"
+    res["what"] = ("plain persistent stream kernels, 16 B per lane, 384 MiB buffers, best of 1/2/4/8 workgroups per CU, on this "
+                   "box.  copy = reads and writes interleaved all the time (what a kernel that overlaps its phases produces); "
+                   "read_then_write = every thread reads its share first and writes afterwards (the chip alternates "
+                   "between two one-directional streams)")
+    return res
+
+
 def extras(pkg, synth, dev, td, to, th, offsets):
     """The other BASELINE.json configs and the small-batch latencies, measured OUTSIDE the timed region (rank 0,
     N=1).  Every entry says what it ran; rates are device-resident unless the entry says "streamed"."""
@@ -416,6 +447,15 @@ def main():
             line["cpu_baseline"] = cpu_baseline(depth, offsets, headers)
         if world == 1 and not args.no_extras and not rehearsal:
             line["extras"] = extras(pkg, synth, dev, td, to, th, offsets)
+            sc = stream_ceilings()
+            if sc:
+                line["extras"]["stream_ceilings"] = sc
+                cp = max(sc.get("copy_nt", 0.0), sc.get("copy", 0.0))
+                if cp > 0:   # interleaved reads and writes are the fair comparison for this kernel
+                    line["roofline"]["frac_of_copy_stream_this_box"] = round(line["roofline"]["achieved"] / cp, 4)
+                    if traffic:
+                        line["roofline"]["traffic_rate_GBps"] = round(traffic / (mean_ms * 1e-3) / 1e9, 1)
+                        line["roofline"]["traffic_rate_over_copy_stream"] = round(traffic / (mean_ms * 1e-3) / 1e9 / cp, 4)
         print(json.dumps(line), flush=True)
 
     if dist is not None:

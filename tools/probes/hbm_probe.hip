@@ -68,6 +68,33 @@ __global__ __launch_bounds__(1024) void k_volumes(f4 *__restrict__ out, int n_fr
   }
 }
 
+// The same volumes written by T threads each (T = 256, 512 or 1024: 4, 2 or 1 volume streams per workgroup), contiguous:
+// does the NUMBER of concurrent streams matter?
+template <bool NT, int T>
+__global__ __launch_bounds__(1024) void k_volumes_t(f4 *__restrict__ out, int n_frames) {
+  constexpr int G = 1024 / T;
+  const int group = threadIdx.x / T, t = threadIdx.x % T;
+  const f4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+  for (int fr = blockIdx.x * G + group; fr < n_frames; fr += gridDim.x * G) {
+    f4 *o = out + (size_t)fr * (3 * 32768 / 4);
+    for (int i = t; i < 3 * 8192; i += T) {
+      if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+    }
+  }
+}
+// ... and volumes written cooperatively by W consecutive workgroups (W = 2, 4, 8): fewer, faster streams
+template <bool NT, int W>
+__global__ __launch_bounds__(1024) void k_volumes_w(f4 *__restrict__ out, int n_frames) {
+  const int team = blockIdx.x / W, part = blockIdx.x % W, teams = gridDim.x / W;
+  const f4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+  for (int fr = team; fr < n_frames; fr += teams) {
+    f4 *o = out + (size_t)fr * (3 * 32768 / 4);
+    for (int i = part * 1024 + threadIdx.x; i < 3 * 8192; i += 1024 * W) {
+      if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+    }
+  }
+}
+
 int main(int argc, char **argv) {
   const size_t bytes = (argc > 1 ? atoll(argv[1]) : 1024) << 20;
   const size_t n4 = bytes / 16;
@@ -114,6 +141,15 @@ int main(int argc, char **argv) {
     runv("planes nt, start slice rotated x5", [&] { hipLaunchKernelGGL((k_volumes<true, true, 5>), grid, 1024, 0, 0, b, nf); });
     runv("planes nt, start slice rotated x2", [&] { hipLaunchKernelGGL((k_volumes<true, true, 2>), grid, 1024, 0, 0, b, nf); });
     runv("planes, start slice rotated x5", [&] { hipLaunchKernelGGL((k_volumes<false, true, 5>), grid, 1024, 0, 0, b, nf); });
+    runv("contiguous nt, 256 thr/volume", [&] { hipLaunchKernelGGL((k_volumes_t<true, 256>), grid, 1024, 0, 0, b, nf); });
+    runv("contiguous nt, 512 thr/volume", [&] { hipLaunchKernelGGL((k_volumes_t<true, 512>), grid, 1024, 0, 0, b, nf); });
+    runv("contiguous nt, 1024 thr/volume", [&] { hipLaunchKernelGGL((k_volumes_t<true, 1024>), grid, 1024, 0, 0, b, nf); });
+    runv("contiguous, 1024 thr/volume", [&] { hipLaunchKernelGGL((k_volumes_t<false, 1024>), grid, 1024, 0, 0, b, nf); });
+    runv("nt, 2 workgroups/volume", [&] { hipLaunchKernelGGL((k_volumes_w<true, 2>), grid, 1024, 0, 0, b, nf); });
+    runv("nt, 4 workgroups/volume", [&] { hipLaunchKernelGGL((k_volumes_w<true, 4>), grid, 1024, 0, 0, b, nf); });
+    runv("nt, 8 workgroups/volume", [&] { hipLaunchKernelGGL((k_volumes_w<true, 8>), grid, 1024, 0, 0, b, nf); });
+    runv("nt, 32 workgroups/volume", [&] { hipLaunchKernelGGL((k_volumes_w<true, 32>), grid, 1024, 0, 0, b, nf); });
+    runv("nt, 256 workgroups/volume", [&] { hipLaunchKernelGGL((k_volumes_w<true, 256>), grid, 1024, 0, 0, b, nf); });
   }
   CK(hipDeviceSynchronize());
   printf("device: %s, %d CUs\n", p.name, p.multiProcessorCount);
