@@ -43,8 +43,8 @@ def make_frames(n):
 
 for rnd in range(rounds):
     n = int(rng.choice([1, 3, 17, 100, 128, 129, 300, 700]))
-    R = int(rng.choice([16, 32, 32, 32, 40, 64]))
-    if R == 64: n = min(n, 300)
+    R = int(rng.choice([16, 32, 32, 32, 40, 64] if rng.random() < 0.85 else [4, 8, 12, 20, 24, 28, 48, 96, 128]))
+    if R >= 64: n = min(n, 300 if R == 64 else 17)
     layout = str(rng.choice(["czyx", "cxyz"]))
     cam = ocam = None
     if rng.random() < 0.3:   # other camera constants: focal, principal point, invalid-depth threshold, truncation (voxels)
