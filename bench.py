@@ -267,6 +267,31 @@ def extras(pkg, synth, dev, td, to, th, offsets):
         "what": "BASELINE configs[2]: 8,500 MSRA-like crops from a page-locked pack through dataset.VoxelLoader "
                 "(ONE hipMemcpyAsync per batch on a copy stream, overlapped with the fused voxelizer + labels, which reads "
                 "offsets / headers / labels from page-locked host memory); PCIe-bound"}
+    # configs[2] with the subject RESIDENT on the GPU (ResidentLoader / tsdf_voxelize_indexed_hip): the pack is uploaded
+    # once, shuffled batches are drawn by index on the device; next to it what shuffling costs the host-fed loader
+    def epochs(ld, k):
+        r = []
+        for _ in range(k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            seen = 0
+            for batch in ld:
+                seen += batch.tsdf.shape[0]
+            torch.cuda.synchronize()
+            r.append(seen / (time.perf_counter() - t0))
+        return r
+    rl = pkg.ResidentLoader(ds, batch_size=1024, device=dev, shuffle=True)
+    r1024 = epochs(rl, 5)
+    r16 = epochs(pkg.ResidentLoader(ds, batch_size=16, device=dev, shuffle=True), 3)
+    h1024 = epochs(pkg.VoxelLoader(ds, batch_size=1024, device=dev, shuffle=True, max_pixels=1024 * 160 * 160), 3)
+    ex["configs[2]_resident_shuffled"] = {
+        "frames": 8500, "resident_bytes": rl.resident_bytes(),
+        "batch_1024_crops_per_s": round(max(r1024[1:])), "batch_16_crops_per_s": round(max(r16[1:])),
+        "host_fed_shuffled_batch_1024_crops_per_s": round(max(h1024[1:])),
+        "what": "BASELINE configs[2] with the subject's pack resident in HBM (uploaded once; all of MSRA is 4.8 GB): shuffled "
+                "batches drawn by index on the device, labels included (dataset.ResidentLoader); and the same shuffled "
+                "batches through VoxelLoader, whose host gathers the crops before uploading them"}
+    del rl
     # the same pipeline over four subjects' worth of frames: the 8,500-frame number above carries the fixed cost of
     # starting and draining a 9-batch epoch
     del loader, ds

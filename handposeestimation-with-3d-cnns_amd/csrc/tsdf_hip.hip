@@ -1193,6 +1193,8 @@ struct KArgs {
   unsigned int *queue;    // this launch's work-queue word, or null: CU-local queues (see the kernel)
   const double *xforms;
   int64_t depth_len;
+  const int64_t *index;   // tsdf_voxelize_indexed_hip: batch position -> frame of the resident pack (else null)
+  int64_t n_src;          // ... and the number of frames in that pack
   const float *gt;        // labels (optional)
   float *gt_nor, *gt_aug;
   int n_joints, clamp;
@@ -1215,7 +1217,29 @@ struct FrameHdr {
   int l, t, r, b;
   int pad;
   int64_t off0, off1;
+  int64_t src;  // where the frame's offsets / header / labels are read: `frame`, or index[frame] (indexed entry)
 };
+
+// The frame's header and offsets.  Indexed entry: batch position fr reads pack frame index[fr]; an index outside the
+// pack leaves off1 < off0, which frame_from_header turns into TSDF_FRAME_BAD_HEADER (nothing is read through it).
+__device__ __forceinline__ void fetch_header(const KArgs &a, const int64_t *__restrict__ in_offsets,
+                                             const int32_t *__restrict__ in_headers, int fr, FrameHdr &m) {
+  int64_t src = fr;
+  bool ok = true;
+  if (a.index) {
+    src = a.index[fr];
+    ok = src >= 0 && src < a.n_src;
+    if (!ok) src = 0;
+  }
+  const int32_t *h = in_headers + 6 * src;
+  m.l = h[2];
+  m.t = h[3];
+  m.r = h[4];
+  m.b = h[5];
+  m.off0 = in_offsets[src];
+  m.off1 = ok ? in_offsets[src + 1] : m.off0 - 1;
+  m.src = src;
+}
 
 // Tail help: a group that finds the queue empty does not leave at once.  It raises idle[] and waits; the
 // CU's other group, on reaching phase 2 of what is then necessarily its last frame, sees the flag, posts
@@ -1390,13 +1414,13 @@ __device__ __forceinline__ void write_frame_outputs(const KArgs &a, int frame, c
 // Labels: pre/joint_nor.py:8-18 + the clamp of 3D_CNN/train.py:241-242, float32, three separately rounded
 // operations; AUG maps the joints with the frame's forward map first (pre/process.py:232-249 does it with the
 // cloud's S and R).  Frames that are not OK get 0.5 (see include/tsdf.h).
-__device__ __forceinline__ void write_labels(const KArgs &a, int frame, const Grid &g, int status, const double *xf,
-                                             int tid, int T) {
+__device__ __forceinline__ void write_labels(const KArgs &a, int frame, int64_t src, const Grid &g, int status,
+                                             const double *xf, int tid, int T) {
   if (!a.gt) return;
   const int nc = 3 * a.n_joints;
   for (int e = tid; e < nc; e += T) {
     const int c = e % 3;
-    const float *gj = a.gt + (int64_t)frame * nc + (e - c);
+    const float *gj = a.gt + src * nc + (e - c);
     float v = gj[c];
     if (xf) v = (float)affine_row(xf + 4 * c, (double)gj[0], (double)gj[1], (double)gj[2]);
     if (a.gt_aug) a.gt_aug[(int64_t)frame * nc + e] = v;  // the joints in the grid's frame (plain path: a copy)
@@ -1622,16 +1646,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
       FrameHdr m;
       m.frame = fr < n ? fr : -1;
       m.l = m.t = m.r = m.b = m.pad = 0;
-      m.off0 = m.off1 = 0;
-      if (fr < n) {
-        const int32_t *h = in_headers + 6 * (int64_t)fr;
-        m.l = h[2];
-        m.t = h[3];
-        m.r = h[4];
-        m.b = h[5];
-        m.off0 = in_offsets[fr];
-        m.off1 = in_offsets[fr + 1];
-      }
+      m.off0 = m.off1 = m.src = 0;
+      if (fr < n) fetch_header(a, in_offsets, in_headers, fr, m);
       if (lane == 0) {
         ctl.hdr[group] = m;
         ctl.cap_fail[group] = 0;
@@ -1686,7 +1702,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
     }
 
     if (gtid == 0) write_frame_outputs(a, frame, g, ab, status);
-    write_labels(a, frame, g, status, xf, gtid, kGW);
+    write_labels(a, frame, fh.src, g, status, xf, gtid, kGW);
 
     // the frame's spans are in the pool iff capture was on and every row fitted (group-uniform: the flag
     // was written before the extents barrier)
@@ -1879,15 +1895,9 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
   if (tid == 0) ctl.cap_fail[0] = 0;
   FrameHdr fh;
   {
-    const int32_t *h = in_headers + 6 * (int64_t)frame;  // uniform: scalar loads
     fh.frame = frame;
-    fh.l = h[2];
-    fh.t = h[3];
-    fh.r = h[4];
-    fh.b = h[5];
     fh.pad = 0;
-    fh.off0 = in_offsets[frame];
-    fh.off1 = in_offsets[frame + 1];
+    fetch_header(a, in_offsets, in_headers, frame, fh);  // uniform: scalar loads
   }
   __syncthreads();
   TSDF_STAMP(0, 0);
@@ -1990,7 +2000,7 @@ __global__ __launch_bounds__(kWG) void tsdf_split_kernel(const KArgs a, const fl
   TSDF_STAMP(0, 4);
   if (part == 0) {
     if (tid == 0) write_frame_outputs(a, frame, g, ab, status);
-    write_labels(a, frame, g, status, xf, tid, kWG);
+    write_labels(a, frame, fh.src, g, status, xf, tid, kWG);
   }
   if (!want_vol) return;
   if (status != TSDF_FRAME_OK) {
@@ -2283,6 +2293,8 @@ struct RunOpts {
   const double *xforms = nullptr;
   const tsdf_labels *labels = nullptr;
   int32_t *pixmap = nullptr;
+  const int64_t *index = nullptr;  // indexed entry
+  int64_t n_src = 0;
 };
 
 int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
@@ -2328,6 +2340,8 @@ int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const
   a.grid_in = o.grid_in;
   a.xforms = o.xforms;
   a.depth_len = depth_len;
+  a.index = o.index;
+  a.n_src = o.n_src;
   if (o.labels) {
     a.gt = o.labels->d_gt;
     a.gt_nor = o.labels->d_out_gt_nor;
@@ -2405,6 +2419,20 @@ int tsdf_voxelize_labels_hip(const float *d_depth, int64_t depth_len, const int6
   if (!labels) return TSDF_ERR_INVALID_ARG;
   RunOpts o;
   o.labels = labels;
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+             d_out_mid_p, d_out_status, o);
+}
+
+int tsdf_voxelize_indexed_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
+                              int64_t n_pack, const int64_t *d_index, int n, int R, const tsdf_cam *cam, int layout,
+                              void *hip_stream, float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p,
+                              int32_t *d_out_status, const tsdf_labels *labels) {
+  if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !d_index)) return TSDF_ERR_INVALID_ARG;
+  if (n_pack < 0 || (n > 0 && n_pack == 0)) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.labels = labels;
+  o.index = d_index;
+  o.n_src = n_pack;
   return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
              d_out_mid_p, d_out_status, o);
 }

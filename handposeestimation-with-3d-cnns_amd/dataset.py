@@ -35,7 +35,8 @@ import torch
 import torch.utils.data as data
 
 from . import packing, shard
-from .voxelize import TsdfBatch, denormalize_joints, normalize_joints, voxelize, voxelize_labels  # noqa: F401
+from .voxelize import (TsdfBatch, denormalize_joints, normalize_joints, voxelize, voxelize_indexed,  # noqa: F401
+                       voxelize_labels)
 
 
 def _subset(size: str) -> Tuple[int, int]:
@@ -375,6 +376,80 @@ class VoxelLoader:
         finally:
             stop.set()
             t.join()
+
+
+class ResidentLoader:
+    """Batches of voxel grids from a dataset that LIVES ON THE GPU.
+
+    All of MSRA is 76.5 k crops = 4.8 GB; an MI355X has 288 GB.  So instead of feeding crops over the link batch after
+    batch (:class:`VoxelLoader`: PCIe-bound, and for shuffled batches bound by the host's gather) the packs are uploaded
+    ONCE and every batch is drawn by index on the device (``tsdf_voxelize_indexed_hip``): a training step sends n frame
+    indices, nothing else.  Same arguments, same batches (:func:`plan_batches`) and same :class:`VoxelBatch` as
+    ``VoxelLoader``; the dataset must be pack-backed (``MSRADepthDataset(packed_dir=...)`` / ``from_packs``).
+    """
+
+    def __init__(self, dataset: MSRADepthDataset, batch_size: int, device, res: int = 32, shuffle: bool = False,
+                 seed: int = 0, drop_last: bool = False, rank: int = 0, world: int = 1, labels: bool = True,
+                 clamp: bool = True, layout: str = "czyx"):
+        if not dataset.packed:
+            raise ValueError("ResidentLoader needs a pack-backed dataset (packing.pack_tree + packed_dir=, or from_packs)")
+        self.ds, self.bs, self.device, self.res = dataset, int(batch_size), torch.device(device), res
+        self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
+        self.rank, self.world = rank, world
+        self.labels, self.clamp, self.layout = labels, clamp, layout
+        self.epoch = 0
+        self._dev = None   # (depth, offsets, headers, gt) of all packs, on the device
+        self._g = None     # dataset frame -> frame of the concatenated packs
+        self._idx = None   # two pinned index buffers + the events of the launches that read them
+
+    def resident_bytes(self) -> int:
+        return sum(4 * int(pk.depth.size) for pk in self.ds.packs)
+
+    def _upload(self):
+        packs = self.ds.packs
+        px = np.array([int(pk.depth.size) for pk in packs], np.int64)
+        nf = np.array([len(pk) for pk in packs], np.int64)
+        pbase = np.concatenate([[0], np.cumsum(px)])
+        fbase = np.concatenate([[0], np.cumsum(nf)])
+        depth = torch.empty(int(pbase[-1]), dtype=torch.float32, device=self.device)
+        for k, pk in enumerate(packs):   # (a memory-mapped pack is read here, once)
+            depth[int(pbase[k]):int(pbase[k + 1])].copy_(torch.from_numpy(np.ascontiguousarray(pk.depth)))
+        off = np.concatenate([np.asarray(pk.offsets[:-1], np.int64) + pbase[k] for k, pk in enumerate(packs)]
+                             + [pbase[-1:]])
+        hdr = np.concatenate([np.asarray(pk.headers, np.int32).reshape(-1, 6) for pk in packs])
+        gt = np.concatenate([np.asarray(pk.gt, np.float32).reshape(len(pk), -1) if pk.gt is not None
+                             else np.zeros((len(pk), 63), np.float32) for pk in packs])
+        self._dev = (depth, torch.from_numpy(off).to(self.device), torch.from_numpy(np.ascontiguousarray(hdr)).to(self.device),
+                     torch.from_numpy(np.ascontiguousarray(gt)).to(self.device))
+        self._g = fbase[self.ds._pack_of] + self.ds._local
+        self._idx = [(torch.empty(self.bs, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        self._used = [False, False]
+
+    def _batches(self) -> List[np.ndarray]:
+        return plan_batches(len(self.ds), self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch,
+                            self.drop_last, self.ds.pixels())
+
+    def __len__(self) -> int:
+        return len(self._batches())
+
+    def __iter__(self) -> Iterator[VoxelBatch]:
+        batches = self._batches()
+        self.epoch += 1
+        if self._dev is None:
+            self._upload()
+        depth, off, hdr, gt = self._dev
+        cur = torch.cuda.current_stream(self.device)
+        for k, b in enumerate(batches):
+            h_idx, done = self._idx[k & 1]
+            if self._used[k & 1]:
+                done.synchronize()          # the launch that read this index buffer two batches ago
+            n = int(b.size)
+            h_idx.numpy()[:n] = self._g[b]
+            out, gt_nor, g = voxelize_indexed(depth, off, hdr, h_idx[:n], gt, res=self.res, layout=self.layout,
+                                              clamp=self.clamp, gt_copy=True)
+            done.record(cur)
+            self._used[k & 1] = True
+            yield VoxelBatch(out.tsdf, g, out.max_l, out.mid_p, out.status, gt_nor if self.labels else None)
 
 
 class MSRA_Dataset(data.Dataset):

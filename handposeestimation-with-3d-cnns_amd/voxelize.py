@@ -188,6 +188,48 @@ def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.T
     return (out, gt_nor, gt_dev) if gt_copy else (out, gt_nor)
 
 
+def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, index: torch.Tensor,
+                     gt: Optional[torch.Tensor] = None, res: int = 32, layout: str = "czyx",
+                     cam: Optional[_lib.TsdfCam] = None, clamp: bool = True, out: Optional[TsdfBatch] = None,
+                     gt_copy: bool = False):
+    """A batch drawn by index from a pack that lives on the GPU (``tsdf_voxelize_indexed_hip``): ``depth`` /
+    ``offsets[N+1]`` / ``headers[N,6]`` (and ``gt[N,3J]``) describe the whole pack, uploaded once; frame i of the batch is
+    pack frame ``index[i]`` (int64[n], any order — a shuffled minibatch; device or pinned host memory).  Outputs are in
+    batch order.  Bit-identical to :func:`voxelize_labels` on the gathered frames.  Returns ``TsdfBatch`` without ``gt``,
+    else ``(TsdfBatch, gt_nor)`` or, with ``gt_copy=True``, ``(TsdfBatch, gt_nor, gt_of_the_batch)``."""
+    L = _lib.load()
+    _dev_check("index", index, torch.int64, depth.device if isinstance(depth, torch.Tensor) else None, host_ok=True)
+    if index.dim() != 1:
+        raise ValueError("index must have shape [n]")
+    dev, n_pack, R = _check_inputs(L, depth, offsets, headers, res, layout)
+    n = index.numel()
+    out = _make_out(out, n, R, dev)
+    lab = gt_nor = gt_dev = None
+    if gt is not None:
+        _dev_check("gt", gt, torch.float32, dev, host_ok=True)
+        if gt.dim() < 2 or gt.shape[0] != n_pack:
+            raise ValueError("gt must hold the labels of every frame of the pack: [N, 3*J] or [N, J, 3]")
+        nc = gt.numel() // n_pack if n_pack else 63
+        if nc % 3 or not 1 <= nc // 3 <= 170:
+            raise ValueError("gt must hold 1..170 joints of 3 coordinates per frame")
+        gt_nor = torch.empty((n,) + tuple(gt.shape[1:]), dtype=torch.float32, device=dev)
+        gt_dev = torch.empty_like(gt_nor) if gt_copy else None
+        lab = _lib.TsdfLabels(gt.data_ptr(), nc // 3, 1 if clamp else 0, gt_nor.data_ptr(),
+                              gt_dev.data_ptr() if gt_dev is not None else None)
+    if n:
+        with _Current(dev):
+            rc = L.tsdf_voxelize_indexed_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(),
+                                             n_pack, index.data_ptr(), n, R,
+                                             ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout],
+                                             _raw_stream(dev), out.tsdf.data_ptr(), out.max_l.data_ptr(),
+                                             out.mid_p.data_ptr(), out.status.data_ptr(),
+                                             ctypes.byref(lab) if lab is not None else None)
+        _lib.check(rc, "tsdf_voxelize_indexed_hip")
+    if gt is None:
+        return out
+    return (out, gt_nor, gt_dev) if gt_copy else (out, gt_nor)
+
+
 def normalize_joints(gt: torch.Tensor, max_l: torch.Tensor, mid_p: torch.Tensor, clamp: bool = True,
                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Labels into the voxel cube's [0,1] frame on their own (``tsdf_normalize_joints_hip``):

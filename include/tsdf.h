@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 3
+#define TSDF_ABI_VERSION 4
 
 /* Output volume layouts.  Both hold float32[n][3][R][R][R]; channel c = x,y,z component. */
 enum tsdf_layout {
@@ -234,6 +234,22 @@ int tsdf_voxelize_aug_labels_hip(const float *d_depth, int64_t depth_len, const 
                                  const int32_t *d_headers, int n, int R, const tsdf_cam *cam, int layout,
                                  void *hip_stream, const double *d_xforms, float *d_out_tsdf, float *d_out_max_l,
                                  float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels);
+
+/* ---- ABI v4 addition ----------------------------------------------------------------------------- */
+
+/*
+ * Batches drawn from a pack that is RESIDENT on the device — what replaces "load every npz into RAM" of
+ * 3D_CNN/dataset.py:35,99-117 when the whole dataset fits the GPU (all of MSRA: 76.5 k crops = 4.8 GB of 288 GB):
+ * d_depth / d_offsets[n_pack+1] / d_headers[n_pack][6] (and labels->d_gt[n_pack][3*n_joints]) describe the pack, uploaded
+ * once; frame i of the batch is pack frame d_index[i] (any order, repeats allowed: a shuffled minibatch), so a training step
+ * uploads n indices instead of n crops (d_index may be page-locked host memory like the other metadata).  Outputs are
+ * indexed by batch position.  An index outside [0, n_pack) gives that frame TSDF_FRAME_BAD_HEADER.  labels may be NULL.
+ * Same kernels, same arithmetic: the result equals tsdf_voxelize_labels_hip on the gathered frames bit for bit.
+ */
+int tsdf_voxelize_indexed_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                              const int32_t *d_headers, int64_t n_pack, const int64_t *d_index, int n, int R,
+                              const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf, float *d_out_max_l,
+                              float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels);
 
 /* The normalisation on its own, from max_l / mid_p already on the device (pre/joint_nor.py:8-18), and its
  * inverse for predictions, (pred - 0.5) * max_l + mid_p (3D_CNN/train.py:263-266).  Frames with max_l == 0:

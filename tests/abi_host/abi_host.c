@@ -196,6 +196,53 @@ int main(void) {
       HIP(hipHostFree(h_gt));
       HIP(hipFree(d_copy));
     }
+    /* ABI v4: a batch drawn by index from the resident pack (here: frames 2, 0, 2 and one index outside the pack) */
+    {
+      const int64_t idx[4] = {2, 0, 2, N};
+      int64_t *d_idx;
+      float *d_t4, *d_l4, *d_m4, *d_nor4;
+      int32_t *d_s4;
+      static float got_l4[4], got_nor4[4][3 * J];
+      int32_t got_s4[4];
+      const size_t vol = (size_t)3 * R * R * R;
+      float *v4 = (float *)malloc(sizeof(float) * 4 * vol), *v1 = (float *)malloc(sizeof(float) * N * vol);
+      HIP(hipMalloc((void **)&d_idx, sizeof idx));
+      HIP(hipMalloc((void **)&d_t4, sizeof(float) * 4 * vol));
+      HIP(hipMalloc((void **)&d_l4, sizeof(float) * 4));
+      HIP(hipMalloc((void **)&d_m4, sizeof(float) * 12));
+      HIP(hipMalloc((void **)&d_s4, sizeof(int32_t) * 4));
+      HIP(hipMalloc((void **)&d_nor4, sizeof(float) * 4 * 3 * J));
+      HIP(hipMemcpyAsync(d_idx, idx, sizeof idx, hipMemcpyHostToDevice, stream));
+      tsdf_labels l4 = {d_gt, J, 1, d_nor4, NULL};
+      check(tsdf_voxelize_indexed_hip(d_depth, total, d_off, d_hdr, N, d_idx, 4, R, NULL, 0, stream, d_t4, d_l4, d_m4, d_s4,
+                                      &l4) == TSDF_OK, "tsdf_voxelize_indexed_hip returns TSDF_OK");
+      check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_OK,
+            "  (the whole pack, for comparison)");
+      HIP(hipMemcpyAsync(v4, d_t4, sizeof(float) * 4 * vol, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(v1, d_t, sizeof(float) * N * vol, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(got_l4, d_l4, sizeof got_l4, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(got_s4, d_s4, sizeof got_s4, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(got_nor4, d_nor4, sizeof got_nor4, hipMemcpyDeviceToHost, stream));
+      HIP(hipStreamSynchronize(stream));
+      int same = 1;
+      for (int k = 0; k < 3; ++k) {
+        same &= memcmp(v4 + k * vol, v1 + idx[k] * vol, sizeof(float) * vol) == 0;
+        same &= got_l4[k] == ref_l[idx[k]] && got_s4[k] == TSDF_FRAME_OK;
+        same &= memcmp(got_nor4[k], ref_nor[idx[k]], sizeof(float) * 3 * J) == 0;
+      }
+      check(same, "  frames 2, 0, 2 of the pack: volumes, max_l, labels bit-identical");
+      check(got_s4[3] == TSDF_FRAME_BAD_HEADER, "  an index outside the pack -> TSDF_FRAME_BAD_HEADER");
+      check(tsdf_voxelize_indexed_hip(d_depth, total, d_off, d_hdr, N, NULL, 4, R, NULL, 0, stream, d_t4, d_l4, d_m4, d_s4,
+                                      NULL) == TSDF_ERR_INVALID_ARG, "  NULL index -> TSDF_ERR_INVALID_ARG");
+      free(v4);
+      free(v1);
+      HIP(hipFree(d_idx));
+      HIP(hipFree(d_t4));
+      HIP(hipFree(d_l4));
+      HIP(hipFree(d_m4));
+      HIP(hipFree(d_s4));
+      HIP(hipFree(d_nor4));
+    }
     lab.n_joints = 0;
     check(tsdf_voxelize_labels_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s, &lab) ==
               TSDF_ERR_INVALID_ARG, "n_joints = 0 -> TSDF_ERR_INVALID_ARG");

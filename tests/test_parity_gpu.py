@@ -1116,3 +1116,70 @@ def test_custom_camera_constants(pkg, synth, camv):
         ra = oracle.voxelize_aug(depth, off, hdr, xf, R=32, n_threads=8, cam=cam_o)
         np.testing.assert_array_equal(ga.max_l.cpu().numpy(), ra["max_l"])
         assert np.abs(ga.tsdf.cpu().numpy() - ra["tsdf"]).max() <= TOL
+
+
+def test_indexed_batches_from_a_resident_pack(pkg, synth):
+    """tsdf_voxelize_indexed_hip (ABI v4): the pack lives on the GPU, a batch is a list of frame indices (shuffled, with
+    repeats).  Bit-identical to voxelizing the gathered frames, labels included, on the fused (n = 400) and the split
+    (n = 16, 1) kernels; indices outside the pack mark their frame BAD_HEADER and touch nothing else; the index may be
+    page-locked host memory."""
+    d = dev()
+    N = 500
+    depth, off, hdr = synth.synth_batch(N, "crop", seed0=6100)
+    gt = np.random.default_rng(0).normal(0, 90, (N, 63)).astype(np.float32)
+    pk = pkg.packing.PackedFrames(depth, off, hdr, gt)
+    td, to, th, tg = (torch.from_numpy(a).to(d) for a in (depth, off, hdr, gt))
+    rng = np.random.default_rng(1)
+    for n in (400, 16, 1):
+        idx = rng.integers(0, N, n).astype(np.int64)
+        idx[: min(n, 3)] = [N - 1, 0, 7][: min(n, 3)]
+        sub = pk.take(idx)
+        want, want_nor = pkg.voxelize_labels(*(torch.from_numpy(np.ascontiguousarray(a)).to(d)
+                                               for a in (sub.depth, sub.offsets, sub.headers, sub.gt)))
+        for index in (torch.from_numpy(idx).to(d), torch.from_numpy(idx).pin_memory()):
+            got, got_nor, got_gt = pkg.voxelize_indexed(td, to, th, index, tg, gt_copy=True)
+            torch.cuda.synchronize()
+            for a, b in zip(want, got):
+                assert torch.equal(a, b)
+            assert torch.equal(want_nor, got_nor) and torch.equal(got_gt.cpu(), torch.from_numpy(gt[idx]))
+        plain = pkg.voxelize_indexed(td, to, th, torch.from_numpy(idx).to(d))          # no labels
+        assert torch.equal(plain.tsdf, want.tsdf)
+    # against the oracle too, other resolution / layout
+    idx = rng.permutation(N)[:40].astype(np.int64)
+    sub = pk.take(idx)
+    got = pkg.voxelize_indexed(td, to, th, torch.from_numpy(idx).to(d), res=40, layout="cxyz")
+    ref = oracle.voxelize(sub.depth, sub.offsets, sub.headers, R=40, layout=1, n_threads=8)
+    np.testing.assert_array_equal(got.max_l.cpu().numpy(), ref["max_l"])
+    assert np.abs(got.tsdf.cpu().numpy() - ref["tsdf"]).max() <= TOL
+    # bad indices
+    bad = np.array([5, -1, N, 9, 1 << 40], np.int64)
+    got = pkg.voxelize_indexed(td, to, th, torch.from_numpy(bad).to(d), tg)
+    torch.cuda.synchronize()
+    assert got[0].status.cpu().tolist() == [0, 2, 2, 0, 2]
+    assert not bool(got[0].tsdf[[1, 2, 4]].any()) and bool(got[0].tsdf[[0, 3]].any())
+    good = pkg.voxelize_indexed(td, to, th, torch.tensor([5, 9], device=d), tg)
+    assert torch.equal(good[0].tsdf, got[0].tsdf[[0, 3]]) and torch.equal(good[1], got[1][[0, 3]])
+    with pytest.raises(ValueError):
+        pkg.voxelize_indexed(td, to, th, torch.from_numpy(idx), tg)       # pageable index
+
+
+def test_resident_loader(pkg, synth):
+    """ResidentLoader: packs uploaded once, shuffled batches drawn by index on the device; same batches and values as
+    VoxelLoader over the same dataset (which gathers on the host and uploads crops), two ranks' shards included."""
+    d = dev()
+    frames = [synth.synth_frame(7000 + i, "crop") for i in range(70)]
+    g = np.random.default_rng(2).normal(0, 70, (70, 63)).astype(np.float32)
+    packs = [pkg.packing.pack_frames(frames[:30]), pkg.packing.pack_frames(frames[30:])]
+    packs[0].gt, packs[1].gt = g[:30], g[30:]
+    ds = pkg.MSRADepthDataset.from_packs(packs)
+    for rank, world in ((0, 1), (1, 2)):
+        kw = dict(batch_size=16, device=d, shuffle=True, seed=3, rank=rank, world=world)
+        a = pkg.VoxelLoader(ds, **kw)
+        b = pkg.ResidentLoader(ds, **kw)
+        assert len(a) == len(b)
+        for epoch in range(2):
+            for x, y in zip(a, b):
+                torch.cuda.synchronize()
+                for u, v in zip(x, y):
+                    assert torch.equal(u, v)
+    assert b.resident_bytes() == sum(4 * f[1].size for f in frames)
