@@ -2437,6 +2437,22 @@ int tsdf_voxelize_indexed_hip(const float *d_depth, int64_t depth_len, const int
              d_out_mid_p, d_out_status, o);
 }
 
+int tsdf_voxelize_indexed_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                                  const int32_t *d_headers, int64_t n_pack, const int64_t *d_index, int n, int R,
+                                  const tsdf_cam *cam, int layout, void *hip_stream, const double *d_xforms,
+                                  float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status,
+                                  const tsdf_labels *labels) {
+  if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !d_index || !d_xforms)) return TSDF_ERR_INVALID_ARG;
+  if (n_pack < 0 || (n > 0 && n_pack == 0) || (reinterpret_cast<uintptr_t>(d_xforms) & 7)) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.labels = labels;
+  o.index = d_index;
+  o.n_src = n_pack;
+  o.xforms = d_xforms;
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+             d_out_mid_p, d_out_status, o);
+}
+
 int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n,
                            int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
                            float *d_out_tsdf, int32_t *d_out_status) {

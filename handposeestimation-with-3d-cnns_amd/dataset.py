@@ -390,9 +390,13 @@ class ResidentLoader:
 
     def __init__(self, dataset: MSRADepthDataset, batch_size: int, device, res: int = 32, shuffle: bool = False,
                  seed: int = 0, drop_last: bool = False, rank: int = 0, world: int = 1, labels: bool = True,
-                 clamp: bool = True, layout: str = "czyx"):
+                 clamp: bool = True, layout: str = "czyx", augment: bool = False):
+        """``augment=True``: every frame of every batch gets a fresh 3-D augmentation with the reference's distributions
+        (``augment.random_affines``, pre/process.py:209-216) about its own un-augmented grid centre, fused into the
+        voxelizer (BASELINE configs[4]); the yielded ``gt`` are then the mapped joints, ``gt_nor`` their labels."""
         if not dataset.packed:
             raise ValueError("ResidentLoader needs a pack-backed dataset (packing.pack_tree + packed_dir=, or from_packs)")
+        self.augment = bool(augment)
         self.ds, self.bs, self.device, self.res = dataset, int(batch_size), torch.device(device), res
         self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.rank, self.world = rank, world
@@ -424,6 +428,12 @@ class ResidentLoader:
         self._g = fbase[self.ds._pack_of] + self.ds._local
         self._idx = [(torch.empty(self.bs, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
         self._used = [False, False]
+        self._mid = None
+        if self.augment:   # the centres the maps turn about: every frame's own grid centre, one AABB launch over the pack
+            from .voxelize import aabb
+            d, o, h, _ = self._dev
+            self._mid = aabb(d, o, h, res=self.res).grid[:, :3].cpu().numpy().astype(np.float64)
+            self._xf = [torch.empty((self.bs, 24), dtype=torch.float64).pin_memory() for _ in range(2)]
 
     def _batches(self) -> List[np.ndarray]:
         return plan_batches(len(self.ds), self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch,
@@ -444,9 +454,16 @@ class ResidentLoader:
             if self._used[k & 1]:
                 done.synchronize()          # the launch that read this index buffer two batches ago
             n = int(b.size)
-            h_idx.numpy()[:n] = self._g[b]
+            gidx = self._g[b]
+            h_idx.numpy()[:n] = gidx
+            xf = None
+            if self.augment:
+                from . import augment as _aug
+                h_xf = self._xf[k & 1]
+                h_xf.numpy()[:n] = _aug.random_affines(self._mid[gidx], rng=(self.seed, self.epoch, self.rank, k))[0]
+                xf = h_xf[:n].to(self.device, non_blocking=True)   # (read per voxel: device memory, not the link)
             out, gt_nor, g = voxelize_indexed(depth, off, hdr, h_idx[:n], gt, res=self.res, layout=self.layout,
-                                              clamp=self.clamp, gt_copy=True)
+                                              clamp=self.clamp, gt_copy=True, xforms=xf)
             done.record(cur)
             self._used[k & 1] = True
             yield VoxelBatch(out.tsdf, g, out.max_l, out.mid_p, out.status, gt_nor if self.labels else None)

@@ -191,12 +191,14 @@ def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.T
 def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, index: torch.Tensor,
                      gt: Optional[torch.Tensor] = None, res: int = 32, layout: str = "czyx",
                      cam: Optional[_lib.TsdfCam] = None, clamp: bool = True, out: Optional[TsdfBatch] = None,
-                     gt_copy: bool = False):
+                     gt_copy: bool = False, xforms: Optional[torch.Tensor] = None):
     """A batch drawn by index from a pack that lives on the GPU (``tsdf_voxelize_indexed_hip``): ``depth`` /
     ``offsets[N+1]`` / ``headers[N,6]`` (and ``gt[N,3J]``) describe the whole pack, uploaded once; frame i of the batch is
     pack frame ``index[i]`` (int64[n], any order — a shuffled minibatch; device or pinned host memory).  Outputs are in
     batch order.  Bit-identical to :func:`voxelize_labels` on the gathered frames.  Returns ``TsdfBatch`` without ``gt``,
-    else ``(TsdfBatch, gt_nor)`` or, with ``gt_copy=True``, ``(TsdfBatch, gt_nor, gt_of_the_batch)``."""
+    else ``(TsdfBatch, gt_nor)`` or, with ``gt_copy=True``, ``(TsdfBatch, gt_nor, gt_of_the_batch)``.
+    ``xforms`` float64[n,24] on the GPU (one map per batch position, as for :func:`voxelize_aug`) adds the fused 3-D
+    augmentation: the labels are then mapped with it, ``gt_of_the_batch`` is ``T(joints)``."""
     L = _lib.load()
     _dev_check("index", index, torch.int64, depth.device if isinstance(depth, torch.Tensor) else None, host_ok=True)
     if index.dim() != 1:
@@ -205,6 +207,10 @@ def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.
     n = index.numel()
     out = _make_out(out, n, R, dev)
     lab = gt_nor = gt_dev = None
+    if xforms is not None:
+        _dev_check("xforms", xforms, torch.float64, dev)
+        if xforms.numel() != 24 * n:
+            raise ValueError("xforms must have shape [n, 24] (forward rows then inverse rows)")
     if gt is not None:
         _dev_check("gt", gt, torch.float32, dev, host_ok=True)
         if gt.dim() < 2 or gt.shape[0] != n_pack:
@@ -218,12 +224,14 @@ def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.
                               gt_dev.data_ptr() if gt_dev is not None else None)
     if n:
         with _Current(dev):
-            rc = L.tsdf_voxelize_indexed_hip(depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(),
-                                             n_pack, index.data_ptr(), n, R,
-                                             ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout],
-                                             _raw_stream(dev), out.tsdf.data_ptr(), out.max_l.data_ptr(),
-                                             out.mid_p.data_ptr(), out.status.data_ptr(),
-                                             ctypes.byref(lab) if lab is not None else None)
+            head = (depth.data_ptr(), depth.numel(), offsets.data_ptr(), headers.data_ptr(), n_pack, index.data_ptr(), n, R,
+                    ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], _raw_stream(dev))
+            tail = (out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr(),
+                    ctypes.byref(lab) if lab is not None else None)
+            if xforms is None:
+                rc = L.tsdf_voxelize_indexed_hip(*head, *tail)
+            else:
+                rc = L.tsdf_voxelize_indexed_aug_hip(*head, xforms.data_ptr(), *tail)
         _lib.check(rc, "tsdf_voxelize_indexed_hip")
     if gt is None:
         return out

@@ -251,6 +251,14 @@ int tsdf_voxelize_indexed_hip(const float *d_depth, int64_t depth_len, const int
                               const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf, float *d_out_max_l,
                               float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels);
 
+/* The same with the 3-D augmentation of tsdf_voxelize_aug_hip: d_xforms float64[n][24] (device memory) holds one map per
+ * BATCH position; labels (may be NULL) are those of the pack, mapped and normalised as by tsdf_voxelize_aug_labels_hip. */
+int tsdf_voxelize_indexed_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                                  const int32_t *d_headers, int64_t n_pack, const int64_t *d_index, int n, int R,
+                                  const tsdf_cam *cam, int layout, void *hip_stream, const double *d_xforms,
+                                  float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status,
+                                  const tsdf_labels *labels);
+
 /* The normalisation on its own, from max_l / mid_p already on the device (pre/joint_nor.py:8-18), and its
  * inverse for predictions, (pred - 0.5) * max_l + mid_p (3D_CNN/train.py:263-266).  Frames with max_l == 0:
  * 0.5 / mid_p respectively. */

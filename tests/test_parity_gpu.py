@@ -1183,3 +1183,42 @@ def test_resident_loader(pkg, synth):
                 for u, v in zip(x, y):
                     assert torch.equal(u, v)
     assert b.resident_bytes() == sum(4 * f[1].size for f in frames)
+
+
+def test_indexed_batches_with_fused_augmentation(pkg, synth):
+    """tsdf_voxelize_indexed_aug_hip: index + per-batch-position maps == tsdf_voxelize_aug_labels_hip on the gathered
+    frames, bit for bit (fused and split kernels); ResidentLoader(augment=True) draws reference-distribution maps about
+    each frame's own grid centre and yields mapped joints + their labels, reproducibly per (seed, epoch)."""
+    d = dev()
+    N = 300
+    depth, off, hdr = synth.synth_batch(N, "crop", seed0=6400)
+    gt = np.random.default_rng(4).normal(0, 90, (N, 63)).astype(np.float32)
+    pk = pkg.packing.PackedFrames(depth, off, hdr, gt)
+    td, to, th, tg = (torch.from_numpy(a).to(d) for a in (depth, off, hdr, gt))
+    mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
+    rng = np.random.default_rng(5)
+    for n, R in ((200, 32), (12, 64)):
+        idx = rng.integers(0, N, n).astype(np.int64)
+        xf = torch.from_numpy(pkg.augment.random_affines(mid[idx], rng=int(n))[0]).to(d)
+        sub = pk.take(idx)
+        sd, so, sh, sg = (torch.from_numpy(np.ascontiguousarray(a)).to(d) for a in (sub.depth, sub.offsets, sub.headers, sub.gt))
+        want, want_nor, want_aug = pkg.voxelize_aug(sd, so, sh, xf, res=R, gt=sg)
+        got, got_nor, got_aug = pkg.voxelize_indexed(td, to, th, torch.from_numpy(idx).to(d), tg, res=R, xforms=xf, gt_copy=True)
+        torch.cuda.synchronize()
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        assert torch.equal(want_nor, got_nor) and torch.equal(want_aug, got_aug)
+    ds = pkg.MSRADepthDataset.from_packs([pk])
+    runs = []
+    for _ in range(2):
+        ld = pkg.ResidentLoader(ds, batch_size=64, device=d, shuffle=True, seed=9, augment=True)
+        runs.append([tuple(t.clone() for t in b) for b in ld])
+    plain = [b for b in pkg.ResidentLoader(ds, batch_size=64, device=d, shuffle=True, seed=9)]
+    torch.cuda.synchronize()
+    assert len(runs[0]) == 5
+    for b0, b1, p in zip(runs[0], runs[1], plain):
+        for u, v in zip(b0, b1):
+            assert torch.equal(u, v)                       # same seed, same epoch -> same maps
+        ok = b0[4] == 0
+        assert bool(ok.any()) and bool(torch.isfinite(b0[0]).all()) and bool(((b0[5] >= 0) & (b0[5] <= 1)).all())
+        assert not torch.equal(b0[0], p[0]) and not torch.equal(b0[2], p[2])   # the augmentation did something
