@@ -67,7 +67,10 @@ class MSRADepthDataset(data.Dataset):
         if subjects is not None:
             all_sub = list(subjects)
         elif root_path is not None and os.path.isdir(root_path):
-            all_sub = sorted(d for d in os.listdir(root_path) if os.path.isdir(os.path.join(root_path, d)))[:n_sub]
+            # subject directories (MSRA: P0..P8) — not a directory of packs that happens to live inside the tree
+            skip = os.path.abspath(packed_dir) if packed_dir is not None else None
+            all_sub = sorted(d for d in os.listdir(root_path) if os.path.isdir(os.path.join(root_path, d))
+                             and os.path.abspath(os.path.join(root_path, d)) != skip)[:n_sub]
         elif packed_dir is not None:
             all_sub = sorted(f[:-7] for f in os.listdir(packed_dir) if f.endswith(".tsdfpk"))[:n_sub]
         else:
@@ -378,6 +381,38 @@ class VoxelLoader:
             t.join()
 
 
+class ResidentPacks:
+    """The packs of a pack-backed dataset, uploaded to the GPU once: ``depth``, ``offsets[G+1]``, ``headers[G,6]``,
+    ``gt[G,63]`` over the G frames of all packs back to back, and ``frame[d]`` = which of them dataset item d is."""
+
+    def __init__(self, dataset: MSRADepthDataset, device):
+        if not dataset.packed:
+            raise ValueError("a resident dataset needs packs (packing.pack_tree + packed_dir=, or from_packs)")
+        packs = dataset.packs
+        px = np.array([int(pk.depth.size) for pk in packs], np.int64)
+        nf = np.array([len(pk) for pk in packs], np.int64)
+        pbase = np.concatenate([[0], np.cumsum(px)])
+        fbase = np.concatenate([[0], np.cumsum(nf)])
+        self.depth = torch.empty(int(pbase[-1]), dtype=torch.float32, device=device)
+        import warnings
+        with warnings.catch_warnings():      # (a memory-mapped pack is read-only: torch warns, and we only read)
+            warnings.simplefilter("ignore", UserWarning)
+            for k, pk in enumerate(packs):   # (a memory-mapped pack is read here, once)
+                self.depth[int(pbase[k]):int(pbase[k + 1])].copy_(torch.from_numpy(np.ascontiguousarray(pk.depth)))
+        off = np.concatenate([np.asarray(pk.offsets[:-1], np.int64) + pbase[k] for k, pk in enumerate(packs)]
+                             + [pbase[-1:]])
+        hdr = np.concatenate([np.asarray(pk.headers, np.int32).reshape(-1, 6) for pk in packs])
+        gt = np.concatenate([np.asarray(pk.gt, np.float32).reshape(len(pk), -1) if pk.gt is not None
+                             else np.zeros((len(pk), 63), np.float32) for pk in packs])
+        self.offsets = torch.from_numpy(off).to(device)
+        self.headers = torch.from_numpy(np.ascontiguousarray(hdr)).to(device)
+        self.gt = torch.from_numpy(np.ascontiguousarray(gt)).to(device)
+        self.frame = fbase[dataset._pack_of] + dataset._local
+
+    def nbytes(self) -> int:
+        return 4 * self.depth.numel()
+
+
 class ResidentLoader:
     """Batches of voxel grids from a dataset that LIVES ON THE GPU.
 
@@ -410,22 +445,9 @@ class ResidentLoader:
         return sum(4 * int(pk.depth.size) for pk in self.ds.packs)
 
     def _upload(self):
-        packs = self.ds.packs
-        px = np.array([int(pk.depth.size) for pk in packs], np.int64)
-        nf = np.array([len(pk) for pk in packs], np.int64)
-        pbase = np.concatenate([[0], np.cumsum(px)])
-        fbase = np.concatenate([[0], np.cumsum(nf)])
-        depth = torch.empty(int(pbase[-1]), dtype=torch.float32, device=self.device)
-        for k, pk in enumerate(packs):   # (a memory-mapped pack is read here, once)
-            depth[int(pbase[k]):int(pbase[k + 1])].copy_(torch.from_numpy(np.ascontiguousarray(pk.depth)))
-        off = np.concatenate([np.asarray(pk.offsets[:-1], np.int64) + pbase[k] for k, pk in enumerate(packs)]
-                             + [pbase[-1:]])
-        hdr = np.concatenate([np.asarray(pk.headers, np.int32).reshape(-1, 6) for pk in packs])
-        gt = np.concatenate([np.asarray(pk.gt, np.float32).reshape(len(pk), -1) if pk.gt is not None
-                             else np.zeros((len(pk), 63), np.float32) for pk in packs])
-        self._dev = (depth, torch.from_numpy(off).to(self.device), torch.from_numpy(np.ascontiguousarray(hdr)).to(self.device),
-                     torch.from_numpy(np.ascontiguousarray(gt)).to(self.device))
-        self._g = fbase[self.ds._pack_of] + self.ds._local
+        rp = ResidentPacks(self.ds, self.device)
+        self._dev = (rp.depth, rp.offsets, rp.headers, rp.gt)
+        self._g = rp.frame
         self._idx = [(torch.empty(self.bs, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
         self._used = [False, False]
         self._mid = None
@@ -489,7 +511,7 @@ class MSRA_Dataset(data.Dataset):
     """
 
     def __init__(self, root_path, opt=None, train=True, aug=False, device="cuda", block: int = 1024,
-                 packed_dir: Optional[str] = None):
+                 packed_dir: Optional[str] = None, resident: Optional[bool] = None):
         if aug:
             raise NotImplementedError("aug=True: the reference loads '_aug' files its preprocessing cannot produce "
                                       "(data_aug raises AxisError); use voxelize_aug for on-the-fly augmentation")
@@ -505,16 +527,27 @@ class MSRA_Dataset(data.Dataset):
         self._cache: Optional[TsdfBatch] = None
         self._cache_gt: Optional[torch.Tensor] = None
         self._last = -1          # the last index served (a sequential walk is answered from blocks)
+        # resident (default: whenever the dataset is pack-backed): the packs go to the GPU once and a batch is a list of
+        # indices resolved on the device (tsdf_voxelize_indexed_hip) — no crop crosses the link after start-up
+        self.resident = self.raw.packed if resident is None else bool(resident)
+        self._rp: Optional[ResidentPacks] = None
 
     def __len__(self):
         return len(self.raw)
 
     def _load_block(self, blk: int):
         a, b = blk * self.block, min(len(self.raw), (blk + 1) * self.block)
-        pk = self.raw.take(np.arange(a, b))
-        depth, offsets, headers = pk.to_torch(self.device, pin=False, non_blocking=False)
-        self._cache = voxelize(depth, offsets, headers, res=32)
-        self._cache_gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
+        if self.resident:
+            if self._rp is None:
+                self._rp = ResidentPacks(self.raw, self.device)
+            rp = self._rp
+            self._cache, _, self._cache_gt = voxelize_indexed(
+                rp.depth, rp.offsets, rp.headers, torch.from_numpy(rp.frame[a:b]).to(self.device), rp.gt, gt_copy=True)
+        else:
+            pk = self.raw.take(np.arange(a, b))
+            depth, offsets, headers = pk.to_torch(self.device, pin=False, non_blocking=False)
+            self._cache = voxelize(depth, offsets, headers, res=32)
+            self._cache_gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
         self._cache_block = blk
 
     def __getitems__(self, indices):
@@ -524,6 +557,13 @@ class MSRA_Dataset(data.Dataset):
         if idx.size and (idx.min() < 0 or idx.max() >= len(self.raw)):
             raise IndexError(int(idx.max() if idx.max() >= len(self.raw) else idx.min()))
         self._last = int(idx[-1]) if idx.size else self._last
+        if self.resident:
+            if self._rp is None:
+                self._rp = ResidentPacks(self.raw, self.device)
+            rp = self._rp
+            out, _, gt = voxelize_indexed(rp.depth, rp.offsets, rp.headers,
+                                          torch.from_numpy(rp.frame[idx]).to(self.device), rp.gt, gt_copy=True)
+            return [(out.tsdf[k], gt[k], out.max_l[k], out.mid_p[k]) for k in range(idx.size)]
         pk = self.raw.take(idx)
         depth, offsets, headers = pk.to_torch(self.device, pin=False, non_blocking=False)
         out = voxelize(depth, offsets, headers, res=32)

@@ -142,7 +142,9 @@ class PackedFrames:
         depth = np.ascontiguousarray(self.depth, np.float32)
         if offsets.shape != (n + 1,) or offsets[0] != 0 or offsets[-1] != depth.size:
             raise ValueError("offsets do not describe the depth buffer")
-        gt = None if self.gt is None else np.ascontiguousarray(self.gt, np.float32).reshape(n, -1)
+        gt = None if self.gt is None else np.ascontiguousarray(self.gt, np.float32)
+        if gt is not None:
+            gt = gt.reshape(n, gt.size // n if n else (gt.shape[-1] if gt.ndim > 1 else 0))
         gs = np.ascontiguousarray(self.group_start if self.group_start is not None else [0, n], np.int64)
         names = "\n".join(self.group_names or [""] * (gs.size - 1)).encode()
         tmp = path + ".tmp"

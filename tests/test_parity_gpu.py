@@ -404,6 +404,16 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
     for i in range(8):
         assert float(rds[i][2]) == ref["max_l"][i]
     assert blocks == [0, 1]
+    # pack-backed: the packs live on the GPU, items and batches are drawn by index there (resident by default)
+    res_ds = pkg.MSRA_Dataset(str(tmp_path), Opt(), train=True, block=5, packed_dir=str(tmp_path / "packs"))
+    assert res_ds.resident and not rds.resident and len(res_ds) == 8
+    for i in (6, 1, 3, 0, 1, 2, 3, 4, 5):
+        for u, v in zip(res_ds[i], rds[i]):
+            assert torch.equal(u, v)
+    for (t1, g1, l1, m1), (t2, g2, l2, m2) in zip(
+            torch.utils.data.DataLoader(res_ds, batch_size=3, shuffle=True, generator=torch.Generator().manual_seed(8)),
+            torch.utils.data.DataLoader(rds, batch_size=3, shuffle=True, generator=torch.Generator().manual_seed(8))):
+        assert torch.equal(t1, t2) and torch.equal(g1, g2) and torch.equal(l1, l2) and torch.equal(m1, m2)
     with pytest.raises(NotImplementedError):
         pkg.MSRA_Dataset(str(tmp_path), Opt(), aug=True)
 
