@@ -55,16 +55,32 @@ for rnd in range(rounds):
     gt = rng.normal(0, 300, (n, 63)).astype(np.float32)
     td, to, th, tg = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr, gt))
     aug = rng.random() < 0.35
+    indexed = rng.random() < 0.3      # the batch is drawn by index (shuffled, with repeats) from the frames as a resident pack
+    if indexed:
+        pick = rng.integers(0, n, n).astype(np.int64)
+        pack = (td, to, th, tg)
+        lens = np.diff(off)[pick]
+        depth = np.concatenate([depth[off[i]:off[i + 1]] for i in pick]) if n else depth
+        off = np.zeros(n + 1, np.int64); off[1:] = np.cumsum(lens)
+        hdr, gt = hdr[pick], gt[pick]
+        tpick = torch.from_numpy(pick).to(dev)
     with np.errstate(all="ignore"):
         if aug:
             mid = oracle.voxelize(depth, off, hdr, R=R, n_threads=16, cam=ocam)["mid_p"]
             xf = pkg.augment.random_affines(mid, rng=int(rng.integers(1 << 30)))[0]
-            got, g_nor, g_aug = pkg.voxelize_aug(td, to, th, torch.from_numpy(xf).to(dev), res=R, layout=layout, gt=tg, cam=cam)
+            if indexed:
+                got, g_nor, g_aug = pkg.voxelize_indexed(*pack[:3], tpick, pack[3], res=R, layout=layout, cam=cam,
+                                                         xforms=torch.from_numpy(xf).to(dev), gt_copy=True)
+            else:
+                got, g_nor, g_aug = pkg.voxelize_aug(td, to, th, torch.from_numpy(xf).to(dev), res=R, layout=layout, gt=tg, cam=cam)
             ref = oracle.voxelize_aug(depth, off, hdr, xf, R=R, layout=0 if layout == "czyx" else 1, n_threads=16, cam=ocam)
             r_aug = oracle.transform_joints(gt, xf) if hasattr(oracle, "transform_joints") else None
             r_nor = oracle.normalize_joints(r_aug if r_aug is not None else gt, ref["max_l"], ref["mid_p"])
         else:
-            got, g_nor = pkg.voxelize_labels(td, to, th, tg, res=R, layout=layout, cam=cam)
+            if indexed:
+                got, g_nor = pkg.voxelize_indexed(*pack[:3], tpick, pack[3], res=R, layout=layout, cam=cam)
+            else:
+                got, g_nor = pkg.voxelize_labels(td, to, th, tg, res=R, layout=layout, cam=cam)
             ref = oracle.voxelize(depth, off, hdr, R=R, layout=0 if layout == "czyx" else 1, n_threads=16, cam=ocam)
             r_nor = oracle.normalize_joints(gt, ref["max_l"], ref["mid_p"])
     torch.cuda.synchronize()
@@ -81,7 +97,7 @@ for rnd in range(rounds):
     bad += int((err > TOL).sum())
     tot["frames"] += n; tot["voxels"] += n * 3 * R ** 3; tot["ok_frames"] += int(okf.sum()); tot["bad"] += bad
     tot["max_err"] = max(tot["max_err"], float(err.max()))
-    print(f"round {rnd:3d}: n={n:4d} R={R:3d} {layout} {'aug' if aug else 'plain'}{' cam' if cam is not None else ''}  ok frames {int(okf.sum()):4d}  max err {err.max():.2e}  mismatches {bad}", flush=True)
+    print(f"round {rnd:3d}: n={n:4d} R={R:3d} {layout} {'aug' if aug else 'plain'}{' cam' if cam is not None else ''}{' indexed' if indexed else ''}  ok frames {int(okf.sum()):4d}  max err {err.max():.2e}  mismatches {bad}", flush=True)
     if bad:
         print("   first bad frames:", np.flatnonzero(err > TOL)[:5], "seed state differs: rerun with the same arguments to reproduce")
 print(tot, f"{time.time() - t_start:.0f} s")
