@@ -291,6 +291,12 @@ def extras(pkg, synth, dev, td, to, th, offsets):
         "what": "BASELINE configs[2] with the subject's pack resident in HBM (uploaded once; all of MSRA is 4.8 GB): shuffled "
                 "batches drawn by index on the device, labels included (dataset.ResidentLoader); and the same shuffled "
                 "batches through VoxelLoader, whose host gathers the crops before uploading them"}
+    ra = epochs(pkg.ResidentLoader(ds, batch_size=1024, device=dev, shuffle=True, res=64, augment=True), 3)
+    ex["configs[4]_resident_shuffled_aug_r64"] = {
+        "frames": 8500, "batch": 1024, "crops_per_s": round(max(ra[1:])),
+        "what": "BASELINE configs[4] as a training loop would run it: the subject resident in HBM, shuffled batches by index, a "
+                "fresh reference-distribution 3-D augmentation per frame drawn on the host (numpy) and fused into the 64^3 "
+                "voxelizer, mapped joints + labels from the same launch (dataset.ResidentLoader(augment=True, res=64))"}
     del rl
     # the same pipeline over four subjects' worth of frames: the 8,500-frame number above carries the fixed cost of
     # starting and draining a 9-batch epoch
