@@ -553,6 +553,9 @@ class MSRA_Dataset(data.Dataset):
     def __getitems__(self, indices):
         """The frames of one batch, voxelized by one launch (torch's DataLoader calls this with the batch's indices
         when it exists): a list of item tuples, views into the batch's tensors."""
+        if data.get_worker_info() is not None:
+            raise RuntimeError("MSRA_Dataset produces its items on the GPU: use it with num_workers=0 (the reference's "
+                               "default, train.py:38), there is nothing for loader processes to do")
         idx = np.asarray([int(i) for i in indices], np.int64)
         if idx.size and (idx.min() < 0 or idx.max() >= len(self.raw)):
             raise IndexError(int(idx.max() if idx.max() >= len(self.raw) else idx.min()))
