@@ -99,6 +99,8 @@ def load():
     L.tsdf_voxelize_indexed_aug_hip.restype = ctypes.c_int
     L.tsdf_voxelize_indexed_aug_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int,
                                                 cam_p, ctypes.c_int, vp, vp, vp, vp, vp, vp, lab_p]
+    L.tsdf_host_gather_frames.restype = ctypes.c_int
+    L.tsdf_host_gather_frames.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int]
     L.tsdf_normalize_joints_hip.restype = ctypes.c_int
     L.tsdf_normalize_joints_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.tsdf_denormalize_joints_hip.restype = ctypes.c_int

@@ -2392,6 +2392,46 @@ void tsdf_default_cam(tsdf_cam *cam) {
 
 int tsdf_version(void) { return TSDF_ABI_VERSION; }
 
+// Host-side helper of the loaders (no GPU involved): frames index[0..n) of a packed host buffer copied back to back into
+// dst (e.g. a page-locked staging buffer), dst_offsets[n+1] filled in.  `threads` workers split the bytes evenly.
+int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_t n_src, const int64_t *index, int64_t n,
+                            float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads) {
+  if (n < 0 || n_src < 0 || (n > 0 && (!src || !src_offsets || !index || !dst || !dst_offsets))) return TSDF_ERR_INVALID_ARG;
+  if (!dst_offsets) return n == 0 ? TSDF_OK : TSDF_ERR_INVALID_ARG;
+  dst_offsets[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t f = index[i];
+    if (f < 0 || f >= n_src) return TSDF_ERR_INVALID_ARG;
+    const int64_t len = src_offsets[f + 1] - src_offsets[f];
+    if (len < 0) return TSDF_ERR_INVALID_ARG;
+    dst_offsets[i + 1] = dst_offsets[i] + len;
+  }
+  const int64_t total = dst_offsets[n];
+  if (total > dst_capacity) return TSDF_ERR_INVALID_ARG;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  if (total * 4 < (1 << 20)) threads = 1;  // under a megabyte: starting threads costs more than the copy
+  auto work = [&](int t) {
+    // frames whose first element falls into this worker's share of the elements
+    const int64_t lo = total * t / threads, hi = total * (t + 1) / threads;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t a = dst_offsets[i];
+      if (a < lo) continue;
+      if (a >= hi) break;
+      memcpy(dst + a, src + src_offsets[index[i]], sizeof(float) * (size_t)(dst_offsets[i + 1] - a));
+    }
+  };
+  if (threads == 1) {
+    work(0);
+  } else {
+    std::thread pool[64];
+    for (int t = 1; t < threads; ++t) pool[t] = std::thread(work, t);
+    work(0);
+    for (int t = 1; t < threads; ++t) pool[t].join();
+  }
+  return TSDF_OK;
+}
+
 const char *tsdf_strerror(int status) {
   switch (status) {
     case TSDF_OK: return "ok";

@@ -31,6 +31,32 @@ PACK_MAGIC = b"TSDFPK01"
 _ALIGN = 64
 
 
+_GATHER_THREADS = max(1, min(8, (os.cpu_count() or 1)))
+
+
+def _native_gather(pk, idx: np.ndarray, out: np.ndarray, off: np.ndarray) -> bool:
+    """The shuffled-batch gather by ``tsdf_host_gather_frames`` (threads, one memcpy per frame instead of one numpy slice
+    assignment per frame: ~10 us of interpreter each).  False when the library is not built or the arrays are not plain
+    float32 / int64 memory — the caller then copies frame by frame in numpy.  Host memory only: not a compute path."""
+    if idx.size < 4:
+        return False
+    try:
+        from . import _lib
+        L = _lib.load()
+    except (ImportError, OSError):
+        return False
+    src, so = pk.depth, pk.offsets
+    if not (isinstance(src, np.ndarray) and src.dtype == np.float32 and src.flags.c_contiguous
+            and isinstance(so, np.ndarray) and so.dtype == np.int64 and so.flags.c_contiguous
+            and out.dtype == np.float32 and out.flags.c_contiguous and out.flags.writeable):
+        return False
+    idx = np.ascontiguousarray(idx, np.int64)
+    off2 = np.empty_like(off)
+    rc = L.tsdf_host_gather_frames(src.ctypes.data, so.ctypes.data, so.size - 1, idx.ctypes.data, idx.size, out.ctypes.data,
+                                   out.size, off2.ctypes.data, _GATHER_THREADS)
+    return rc == 0 and bool((off2 == off).all())
+
+
 def _pad(n: int) -> int:
     return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
@@ -117,8 +143,9 @@ class PackedFrames:
         np.cumsum(lens, out=off[1:])
         total = int(off[-1])
         out = depth_out[:total] if depth_out is not None else np.empty(total, np.float32)
-        for k, i in enumerate(idx):  # n slice copies (memcpy speed; the index arithmetic above is vectorised)
-            out[off[k]:off[k + 1]] = self.depth[self.offsets[i]:self.offsets[i + 1]]
+        if not _native_gather(self, idx, out, off):
+            for k, i in enumerate(idx):  # n slice copies (the index arithmetic above is vectorised)
+                out[off[k]:off[k + 1]] = self.depth[self.offsets[i]:self.offsets[i + 1]]
         return PackedFrames(out, off, self.headers[idx], None if self.gt is None else self.gt[idx])
 
     def pin(self) -> "PackedFrames":

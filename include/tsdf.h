@@ -259,6 +259,13 @@ int tsdf_voxelize_indexed_aug_hip(const float *d_depth, int64_t depth_len, const
                                   float *d_out_tsdf, float *d_out_max_l, float *d_out_mid_p, int32_t *d_out_status,
                                   const tsdf_labels *labels);
 
+/* Host-side helper for loaders that cannot keep the pack on the device (no GPU involved, callable without one):
+ * frames index[0..n) of a packed HOST buffer (src, src_offsets[n_src+1]) copied back to back into dst — e.g. a page-locked
+ * staging buffer of dst_capacity elements — by `threads` workers; dst_offsets[n+1] receives the new offsets.  Replaces
+ * the per-file reads a shuffled batch costs the reference's loader (3D_CNN/dataset.py:99-117). */
+int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_t n_src, const int64_t *index, int64_t n,
+                            float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads);
+
 /* The normalisation on its own, from max_l / mid_p already on the device (pre/joint_nor.py:8-18), and its
  * inverse for predictions, (pred - 0.5) * max_l + mid_p (3D_CNN/train.py:263-266).  Frames with max_l == 0:
  * 0.5 / mid_p respectively. */

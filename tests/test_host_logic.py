@@ -353,3 +353,35 @@ def test_gt_3d_export_round_trips_through_the_reference_reader(pkg, tmp_path):
         ground_truth[:, :, 2] = -ground_truth[:, :, 2]
         g_t = ground_truth.reshape(-1, 63)
     np.testing.assert_array_equal(g_t, gt)
+
+
+def test_native_gather_equals_numpy_gather(pkg):
+    """PackedFrames.take of a shuffled batch goes through tsdf_host_gather_frames (threads, host memory only) when the
+    library is there: same bytes and offsets as the frame-by-frame numpy copy, into a caller's buffer too; the C entry
+    rejects indices outside the pack and a destination that is too small."""
+    import ctypes
+    packing = pkg.packing
+    rng = np.random.default_rng(12)
+    frames = []
+    for k in range(60):
+        bw, bh = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        frames.append((np.array([320, 240, 3, 4, 3 + bw, 4 + bh], np.int32), rng.normal(400, 30, bw * bh).astype(np.float32)))
+    pk = packing.pack_frames(frames)
+    idx = rng.permutation(60)[:37].astype(np.int64)
+    want = np.concatenate([frames[i][1] for i in idx])
+    got = pk.take(idx)
+    np.testing.assert_array_equal(got.depth, want)
+    np.testing.assert_array_equal(np.diff(got.offsets), [frames[i][1].size for i in idx])
+    np.testing.assert_array_equal(got.headers, np.stack([frames[i][0] for i in idx]))
+    buf = np.full(want.size + 100, -1.0, np.float32)
+    got2 = pk.take(idx, buf)
+    np.testing.assert_array_equal(got2.depth, want)
+    assert (buf[want.size:] == -1.0).all()
+    L = pkg._lib.load()
+    off2 = np.zeros(3, np.int64)
+    bad = np.array([0, 60], np.int64)
+    args = lambda ix, cap: (pk.depth.ctypes.data, pk.offsets.ctypes.data, 60, ix.ctypes.data, ix.size, buf.ctypes.data, cap,
+                            off2.ctypes.data, 4)
+    assert L.tsdf_host_gather_frames(*args(bad, buf.size)) == -1
+    assert L.tsdf_host_gather_frames(*args(np.array([0, 1], np.int64), 1)) == -1
+    assert L.tsdf_host_gather_frames(*args(np.array([5, 5], np.int64), buf.size)) == 0 and off2[2] == 2 * frames[5][1].size
