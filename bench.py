@@ -157,6 +157,8 @@ def stream_ceilings():
     exe = os.path.join(ROOT, "tools", "probes", "hbm_probe.bin")
     if not os.path.exists(exe):
         return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None   # under a profiler: no second GPU program from inside the profiled one
     import subprocess
     try:
         txt = subprocess.run([exe, "384"], capture_output=True, text=True, timeout=120).stdout
