@@ -99,6 +99,54 @@ def test_config2_subject_streamed_through_the_loader(pkg, crops, tmp_path):
     assert max(rates[1:]) > 2.0e5    # PCIe-bound; the floor only catches a broken pipeline (bench.py has the number)
 
 
+def test_config2_subject_resident_and_shuffled(pkg, crops):
+    """configs[2] the MI355X way: the subject's pack uploaded to HBM once (0.53 GB), SHUFFLED batches of 1024 drawn by
+    index on the device (ResidentLoader / tsdf_voxelize_indexed_hip), labels from the same launch.  Every frame is seen
+    exactly once per epoch, properties hold on all of them, a sample equals the oracle, and batches of the reference's
+    size (16) run too."""
+    pk = tiled_pack(pkg, crops, N_P0)
+    rng = np.random.default_rng(1)
+    pk.gt = rng.normal(0, 60, (N_P0, 63)).astype(np.float32)
+    pk.gt[:, 2::3] -= 450.0
+    ds = pkg.MSRADepthDataset.from_packs([pk])
+    loader = pkg.ResidentLoader(ds, batch_size=1024, device=dev(), shuffle=True, seed=4)
+    assert loader.resident_bytes() == 4 * pk.depth.size
+    plan = pkg.dataset.plan_batches(N_P0, 1024, shuffle=True, seed=4, epoch=0, weights=ds.pixels())
+    sample = set(rng.choice(N_P0, 40, replace=False).tolist())
+    rates = []
+    for epoch in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seen = 0
+        for k, batch in enumerate(loader):
+            n = batch.tsdf.shape[0]
+            if epoch == 0:
+                check_properties(batch.tsdf, batch.status, batch.max_l)
+                assert bool(((batch.gt_nor >= 0) & (batch.gt_nor <= 1)).all())
+                ids = plan[k]
+                np.testing.assert_array_equal(batch.gt.cpu().numpy(), pk.gt[ids])
+                for j in [j for j, i in enumerate(ids) if int(i) in sample]:
+                    h, d = pk.frame(int(ids[j]))
+                    ref = oracle.voxelize(d, np.array([0, d.size], np.int64), h[None])
+                    assert np.abs(batch.tsdf[j].cpu().numpy() - ref["tsdf"][0]).max() <= TOL
+                    assert float(batch.max_l[j]) == ref["max_l"][0]
+                    np.testing.assert_array_equal(batch.gt_nor[j].cpu().numpy(),
+                                                  oracle.normalize_joints(pk.gt[ids[j]:ids[j] + 1], ref["max_l"], ref["mid_p"])[0])
+                    sample.discard(int(ids[j]))
+            seen += n
+        torch.cuda.synchronize()
+        rates.append(seen / (time.perf_counter() - t0))
+        assert seen == N_P0
+    assert not sample                                   # every sampled frame came by
+    assert sorted(np.concatenate(plan).tolist()) == list(range(N_P0))
+    small = pkg.ResidentLoader(ds, batch_size=16, device=dev(), shuffle=True, seed=4)
+    n16 = sum(b.tsdf.shape[0] for b in small)
+    torch.cuda.synchronize()
+    assert n16 == N_P0 and len(small) == (N_P0 + 15) // 16
+    print(f"configs[2] resident: {N_P0} crops, shuffled batches of 1024: {max(rates[1:]):.0f} crops/s")
+    assert max(rates[1:]) > 1.0e6    # an order of magnitude above the link-bound loader; bench.py has the number
+
+
 def test_config3_all_subjects_on_one_gpu(pkg, crops):
     """configs[3], one-GPU form: ~76.5 k crops resident, one launch (19 frames per group through the work queue);
     properties on every frame, oracle on a sample, and each of the 8 pixel-balanced rank shards voxelized alone is
