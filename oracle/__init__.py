@@ -19,6 +19,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtsdf_oracle.so")
+# TSDF_ORACLE_SO: another build of the same file (tests/test_tiers_cpu.py runs the golden tests against the
+# AddressSanitizer/UBSan build, `make -C oracle asan`, in a child process)
+_SO_OVERRIDE = os.environ.get("TSDF_ORACLE_SO")
 
 
 class TsdfCam(ctypes.Structure):
@@ -53,8 +56,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_SO)
+        if _SO_OVERRIDE:
+            L = ctypes.CDLL(_SO_OVERRIDE)
+        else:
+            build()
+            L = ctypes.CDLL(_SO)
         fp = ctypes.POINTER(ctypes.c_float)
         ip = ctypes.POINTER(ctypes.c_int32)
         lp = ctypes.POINTER(ctypes.c_int64)

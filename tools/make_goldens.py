@@ -22,6 +22,9 @@ What each fixture pins:
           stored as a witness with that tolerance.
   aug_ref pre/process.py::DataProcess.data_aug run on [1,M,3] clouds with np.random seeded: pins the stretch /
           rotation conventions and the draw order that handposeestimation-with-3d-cnns_amd/augment.py restates.
+  joint_nor_ref  pre/joint_nor.py::normalize (:8-18) RUN on [n,21,3] float32 labels (the one shape it does not raise
+          on: for the [n,63] arrays its callers hold, `joint_nor[i] = ...` cannot broadcast (21,3) into (63,)) with the
+          goldens' own max_l / mid_p plus seeded extra frames: pins the label formula of SURVEY.md 8(f)#4.
   aabb_*  the numba-typing AABB (pre/tsdf_numba.py:84-96,140-141) from
           oracle/tsdf_oracle_np.py — a restatement, not a run (min_max_kernel cannot
           be executed here: no usable numba, no params.py).
@@ -41,6 +44,7 @@ sys.path.insert(0, REF_PRE)
 
 import tsdf_for  # noqa: E402  (the reference)
 import process as ref_process  # noqa: E402  (the reference)
+import joint_nor as ref_joint_nor  # noqa: E402  (the reference)
 
 synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
 from oracle import tsdf_oracle_np as onp  # noqa: E402
@@ -136,6 +140,34 @@ def run_reference_aug(outdir):
     print(f"aug_ref: {len(seeds)} seeded data_aug runs on [1,{M},3] clouds")
 
 
+def run_reference_joint_nor(outdir, golden_scales):
+    """joint_nor_ref.npz: the reference's own normalize (pre/joint_nor.py:8-18) run on float32 [n,21,3] labels.
+    Frames 0..7 use the max_l / mid_p the reference's tsdf_f produced for the volume goldens (same order as
+    MANIFEST.txt), the rest seeded scales; some joints lie outside the cube so that the clamp of
+    3D_CNN/train.py:241-242 (applied by the test to these reference values) has something to do.  The reference
+    stores its float32 results in a float64 array; they are kept as float64 here, untouched."""
+    rng = np.random.default_rng(777)
+    n_extra = 24
+    max_l = np.concatenate([np.array([g[0] for g in golden_scales], np.float32),
+                            rng.uniform(80, 400, n_extra).astype(np.float32)])
+    mid_p = np.concatenate([np.stack([g[1] for g in golden_scales]).astype(np.float32),
+                            (rng.normal(0, 80, (n_extra, 3)) + [0, 0, -420]).astype(np.float32)])
+    n = len(max_l)
+    gt = (mid_p[:, None, :] + rng.normal(0, 0.35, (n, 21, 3)) * max_l[:, None, None]).astype(np.float32)
+    want = ref_joint_nor.normalize(gt.copy(), max_l, mid_p)
+    assert want.shape == (n, 21, 3) and want.dtype == np.float64
+    assert (want < 0).any() and (want > 1).any()
+    np.savez_compressed(os.path.join(outdir, "joint_nor_ref.npz"), gt=gt, max_l=max_l, mid_p=mid_p, joint_nor=want)
+    # the [n,63] form its callers hold (pre/joint_nor.py:42-45 feeds np.load of ground_truth/*.npy) does not run:
+    try:
+        ref_joint_nor.normalize(gt.reshape(n, 63).copy(), max_l, mid_p)
+        raise AssertionError("normalize accepted [n,63]")
+    except ValueError:
+        pass
+    print(f"joint_nor_ref: {n} frames x 21 joints through pre/joint_nor.py::normalize "
+          f"({int((want < 0).sum())} coordinates < 0, {int((want > 1).sum())} > 1)")
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -149,16 +181,19 @@ def main():
         frames.append((f"crop_{s}", h, d))
     frames += special_frames()
     names = []
+    scales = []
     for name, h, d in frames:
         g = run_reference(h, d)
+        scales.append((g["max_l"], g["mid_p"]))
         np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **g)
         names.append(name)
         print(f"{name}: bbox {h[4]-h[2]}x{h[5]-h[3]} valid {int(g['n_valid'])} max_l {float(g['max_l']):.4f} "
               f"flips(f32 vs f64 loop) {int(g['n_flip'])} "
               f"|loop32-loop64|max(non-flip) "
               f"{float(np.abs(g['loop32']-g['loop64'])[np.abs(g['loop32']-g['loop64'])<=1e-5].max()):.2e}")
+    run_reference_joint_nor(outdir, scales)
     with open(os.path.join(outdir, "MANIFEST.txt"), "w") as f:
-        f.write("# written by tools/make_goldens.py from /root/reference/pre/{tsdf_for,process}.py\n")
+        f.write("# written by tools/make_goldens.py from /root/reference/pre/{tsdf_for,process,joint_nor}.py\n")
         f.write("# numpy %s\n" % np.__version__)
         for n in names:
             f.write(n + "\n")
