@@ -5,13 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one fused launch of the voxelizer over the rank's batch of 1024 synthetic
-320x240 full-frame depth crops (BASELINE.json configs[1]), inputs already resident in HBM.
-Frames are independent, so N GPUs = N ranks each voxelizing its own 1024-frame shard
-(weak scaling, no data-path collective).  RCCL carries the process group, the rendezvous and the
-max-over-ranks of the elapsed time; the barriers that bracket the timed region are node-local
-(NodeBarrier: /dev/shm, microseconds) because a collective barrier costs 0.2-0.4 ms — a tenth of the
-driver's 20-step timed region — and would be charged to N>1 only.  Rank 0 prints ONE JSON line.
+One "step" = LAUNCHES_PER_STEP (16) back-to-back fused launches of the voxelizer, each over the rank's batch of
+1024 synthetic 320x240 full-frame depth crops (BASELINE.json configs[1]), inputs already resident in HBM: 16,384
+frames per GPU and step, ~2.2 ms.  (One launch is 0.135 ms; a timed region of 20 single launches would be 2.7 ms,
+and one 0.3 ms scheduling hiccup in one of eight processes would cost the aggregate 10 %.)
+Frames are independent, so N GPUs = N ranks each voxelizing its own shard (weak scaling, no data-path
+collective).  RCCL carries the process group, the rendezvous and the small gathers of timing numbers; the barriers
+that bracket the timed region are node-local (NodeBarrier: /dev/shm, microseconds) because a collective barrier
+costs 0.2-0.4 ms and would be charged to N>1 only.  Every rank pins itself to the cores of its GPU's NUMA node
+before its first GPU call (the scaling risk of this path is host-side).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline     the fused kernel against the HBM roofline: algorithmic bytes per launch
@@ -21,6 +23,15 @@ Extra objects on that line:
                launches comes from a separate pass with per-launch event pairs).
   cpu_baseline the oracle (C restatement of the reference math, oracle/tsdf_oracle.c) timed on
                this box's host cores on a bounded sample of the same frames (rank 0, N=1 only).
+  per_rank     event-timed ms per step, frames/s and CPU mask of every rank.
+  extras       "configs[3]_sharded" at every N: the 76,500-crop set split by pixel-balanced contiguous shards, every
+               rank voxelizing its own (per-rank and aggregate frames/s); the other BASELINE configs, the loaders and
+               the latency table at N=1.
+
+TSDF_BENCH_REHEARSAL=1  dry run of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, gloo
+                        instead of RCCL).  TSDF_BENCH_DRYRUN=1: no GPU at all — the launches are a host stub; this
+                        exists so that a CPU test can drive this file's own multi-rank code (tests/test_bench_ranks.py).
+                        Neither is ever set by the driver; the line then says so and its numbers mean nothing.
 """
 from __future__ import annotations
 
@@ -37,10 +48,19 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FRAMES_PER_GPU = 1024
+FRAMES_PER_LAUNCH = 1024
+LAUNCHES_PER_STEP = 16
+FRAMES_PER_GPU = FRAMES_PER_LAUNCH          # (name kept: frames resident per GPU = one launch's batch)
 RES = 32
+ALL_SUBJECTS = 76500   # BASELINE configs[3]: all nine MSRA subjects
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0  # what a plain copy kernel reaches on this part (same guide, "measured copy ceiling")
+# SURVEY.md section 6 [probe]: the reference's own Python loop (pre/tsdf_for.py::tsdf_f), measured once in the survey
+# container (1 core of an 8-core Xeon @ 2.1 GHz).  The reference's Python does not travel to the GPU box, so this is
+# quoted, never re-measured; it is what "the reference on a CPU" means — the oracle below is a C port, ~400x faster.
+SURVEY_PY_LOOP = {"tsdf_f_crop_120x140_s_per_frame": 0.104, "tsdf_f_full_320x240_s_per_frame": 0.159,
+                  "DataProcess.process_crop_s_per_frame": 0.185,
+                  "where": "SURVEY.md section 6: survey container, 1 core, Python 3.10 / numpy 2.2 — quoted, not re-measured"}
 
 
 def algorithmic_bytes(offsets: np.ndarray, n: int, R: int) -> int:
@@ -57,6 +77,134 @@ def host_threads() -> int:
     except AttributeError:
         avail = os.cpu_count() or 1
     return max(1, min(avail, 16))
+
+
+# ---- CPU affinity: each rank on the cores next to its GPU --------------------------------------------------------
+def _parse_cpulist(txt: str):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _format_cpulist(cpus) -> str:
+    cpus = sorted(cpus)
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def _visible_devices(env) -> "list[int] | None":
+    """HIP device ordinal -> index among the node's GPUs, from ROCR_VISIBLE_DEVICES (applied by the runtime below HIP)
+    and then HIP_VISIBLE_DEVICES (or its alias CUDA_VISIBLE_DEVICES when that one is unset), when they are plain index
+    lists; None = identity; [] = unreadable (UUIDs or the like)."""
+    order = None
+    hip = env.get("HIP_VISIBLE_DEVICES")
+    for v in (env.get("ROCR_VISIBLE_DEVICES"), hip if hip is not None else env.get("CUDA_VISIBLE_DEVICES")):
+        if v is None or v.strip() == "":
+            continue
+        try:
+            idx = [int(x) for x in v.split(",") if x.strip() != ""]
+        except ValueError:
+            return []
+        if order is None:
+            order = idx
+        elif any(i >= len(order) for i in idx):
+            return []
+        else:
+            order = [order[i] for i in idx]
+    return order
+
+
+def gpu_topology(sysfs: str = "/sys", env=None):
+    """[(pci address, NUMA node, set of local CPUs)] of the GPUs in HIP enumeration order, read from the KFD topology
+    and the PCI devices' sysfs entries WITHOUT touching the GPU (so that it can run before the first HIP call).
+    Empty when anything is unreadable."""
+    env = os.environ if env is None else env
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted(int(d) for d in os.listdir(base) if d.isdigit())
+    except OSError:
+        return []
+    gpus = []
+    for nd in nodes:
+        try:
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, str(nd), "properties")) if len(ln.split()) >= 2)
+        except OSError:
+            return []
+        if int(props.get("simd_count", "0")) <= 0:
+            continue      # a CPU node
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+        pdir = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+        try:
+            cpus = _parse_cpulist(open(os.path.join(pdir, "local_cpulist")).read())
+            numa = int(open(os.path.join(pdir, "numa_node")).read().strip())
+        except (OSError, ValueError):
+            return []
+        gpus.append((bdf, numa, cpus))
+    vis = _visible_devices(env)
+    if vis is not None:
+        if any(i >= len(gpus) for i in vis):
+            return []
+        gpus = [gpus[i] for i in vis]
+    return gpus
+
+
+def plan_affinity(topo, device_of_rank, allowed):
+    """CPU set per local rank: the allowed CPUs local to the rank's GPU; ranks whose GPUs share a NUMA node split that
+    node's CPUs into contiguous equal parts (a part of fewer than 2 CPUs is not worth having: they then share).
+    None for a rank whose GPU is unknown or has no allowed local CPU (the caller leaves its mask alone)."""
+    by_node = {}
+    for r, d in enumerate(device_of_rank):
+        if 0 <= d < len(topo):
+            by_node.setdefault(topo[d][1], []).append(r)
+    plan = [None] * len(device_of_rank)
+    for node, ranks in by_node.items():
+        cpus = sorted(set().union(*[topo[device_of_rank[r]][2] for r in ranks]) & set(allowed))
+        if not cpus:
+            continue
+        per = len(cpus) // len(ranks)
+        for k, r in enumerate(ranks):
+            plan[r] = set(cpus[k * per:(k + 1) * per]) if per >= 2 else set(cpus)
+    return plan
+
+
+def pin_rank(local_rank: int, local_world: int, n_devices_hint: "int | None", rehearsal: bool, sysfs: str = "/sys"):
+    """Pin this process (and every thread it starts later: the HIP runtime's included) to its GPU's cores.  Returns a
+    small report for the JSON line; never raises — an unreadable topology leaves the mask as it is."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        return {"pinned": False, "why": "no sched_getaffinity"}
+    topo = gpu_topology(sysfs)
+    rep = {"pinned": False, "cpus": _format_cpulist(allowed), "gpus_seen": len(topo)}
+    if not topo:
+        rep["why"] = "GPU topology unreadable"
+        return rep
+    ndev = len(topo) if not n_devices_hint else min(len(topo), n_devices_hint)
+    dev_of = [(r % ndev) if rehearsal else r for r in range(local_world)]
+    plan = plan_affinity(topo, dev_of, allowed)
+    mine = plan[local_rank] if local_rank < len(plan) else None
+    if not mine:
+        rep["why"] = "no allowed CPU local to the GPU"
+        return rep
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        rep["why"] = f"sched_setaffinity: {e}"
+        return rep
+    d = dev_of[local_rank]
+    rep.update(pinned=True, cpus=_format_cpulist(mine), numa_node=topo[d][1], pci=topo[d][0])
+    return rep
 
 
 def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
@@ -88,19 +236,22 @@ def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
                   f"runnable: no usable numba, no params.py) over the same 1024 synthetic frames: "
                   f"{nN} frames in {tN:.2f} s on {used} OpenMP threads; single thread {n1} frames in {t1:.2f} s",
         "single_thread_value": round(fps1, 1),
+        "provenance": "a C/OpenMP PORT written for this project, orders of magnitude faster than anything the reference "
+                      "itself can run on a CPU; the reference's own implementation is the Python loop below",
+        "reference_python_loop_frames_per_s_per_core": round(1.0 / SURVEY_PY_LOOP["tsdf_f_full_320x240_s_per_frame"], 2),
+        "reference_python_loop": SURVEY_PY_LOOP,
     }
 
 
 class NodeBarrier:
     """Barrier for the ranks of ONE node through a small file in /dev/shm: every rank publishes the number of the
     barrier it has reached in its own 64-byte slot and spins until all slots show it (a few microseconds, against
-    0.2-0.4 ms for a collective barrier — 10 % of the driver's 20-step timed region).  The frames shard with no
-    exchange, so the only thing a barrier does here is bracket the timed region; RCCL still carries the process
-    group, the one-time rendezvous below and the max-over-ranks of the elapsed time.  `ok` is False (and the caller
-    keeps using the collective barrier) when the ranks do not see each other's writes within the timeout, e.g. ranks
-    in different /dev/shm namespaces."""
+    0.2-0.4 ms for a collective barrier).  The frames shard with no exchange, so the only thing a barrier does here is
+    bracket the timed region; RCCL still carries the process group, the one-time rendezvous below and the gathers of
+    timing numbers.  `ok` is False (and the caller keeps using the collective barrier) when the ranks do not see
+    each other's writes within the timeout, e.g. ranks in different /dev/shm namespaces."""
 
-    def __init__(self, dist, rank, world, collective_barrier, timeout_s=5.0):
+    def __init__(self, dist, rank, world, collective_barrier, flag_device, timeout_s=5.0):
         self.rank, self.world, self.n, self.ok = rank, world, 0, False
         run = os.environ.get("TORCHELASTIC_RUN_ID", "x") + "_" + os.environ.get("MASTER_PORT", "0")
         self.path = f"/dev/shm/tsdf_bench_barrier_{run}"
@@ -113,7 +264,7 @@ class NodeBarrier:
             good = self._wait(timeout_s)
         except OSError:
             good = False
-        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=flag_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         self.ok = bool(flag.item())
         collective_barrier()
@@ -126,14 +277,96 @@ class NodeBarrier:
     def _wait(self, timeout_s=None):
         self.n += 1
         self.slots[self.rank, 0] = self.n
+        col = self.slots[:, 0]
         t0 = time.perf_counter()
-        while int(self.slots[:, 0].min()) < self.n:
+        while int(col.min()) < self.n:
             if timeout_s is not None and time.perf_counter() - t0 > timeout_s:
                 return False
         return True
 
     def __call__(self):
         self._wait()
+
+
+# ---- the device under test, or its host stand-in ------------------------------------------------------------------
+class HipBackend:
+    """The product path: torch for memory / events / streams, the voxelizer through its C ABI."""
+
+    name = "hip"
+
+    def __init__(self, dev_index):
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        self.pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
+
+    def upload(self, depth, offsets, headers):
+        return tuple(torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (depth, offsets, headers))
+
+    def alloc_out(self, d, o, h, res=RES):
+        out = self.pkg.voxelize(d, o, h, res=res)
+        torch.cuda.synchronize()
+        assert bool((out.status == 0).all())
+        return out
+
+    def launch(self, d, o, h, out, res=RES):
+        self.pkg.voxelize(d, o, h, res=res, out=out)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def record(self, ev):
+        ev.record()
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    def pci(self):
+        p = torch.cuda.get_device_properties(self.dev)
+        try:
+            return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        except AttributeError:
+            return None
+
+
+class HostStub:
+    """TSDF_BENCH_DRYRUN=1: no GPU, a launch is a 20 us busy wait.  Exists ONLY so that the multi-rank orchestration of
+    this file (pinning, shard planning, barriers, gathers, the JSON line) can be driven by a CPU test.  It computes
+    nothing: it is not a CPU path of the voxelizer, and the line it produces is marked."""
+
+    name = "host-stub"
+
+    def __init__(self, dev_index):
+        self.dev = torch.device("cpu")
+        self.pkg = None
+
+    def upload(self, depth, offsets, headers):
+        return depth, offsets, headers
+
+    def alloc_out(self, d, o, h, res=RES):
+        return None
+
+    def launch(self, d, o, h, out, res=RES):
+        t = time.perf_counter() + 20e-6
+        while time.perf_counter() < t:
+            pass
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return [0.0]
+
+    def record(self, ev):
+        ev[0] = time.perf_counter()
+
+    def elapsed_ms(self, a, b):
+        return (b[0] - a[0]) * 1e3
+
+    def pci(self):
+        return None
 
 
 def _time_launches(fn, k, warm=3):
@@ -183,10 +416,126 @@ def stream_ceilings():
     return res
 
 
+# ---- BASELINE configs[3]: all nine subjects, frame-sharded across the ranks ------------------------------------------
+N_DISTINCT_CROPS = 2048
+
+
+def crop_lengths(synth):
+    """Pixels per frame of the 76,500-crop set WITHOUT generating a frame: the set is N_DISTINCT_CROPS seeded MSRA-like
+    crops repeated; a crop's size is the first thing its generator draws (synth.synth_frame)."""
+    lens = np.empty(N_DISTINCT_CROPS, np.int64)
+    for i in range(N_DISTINCT_CROPS):
+        rng = np.random.default_rng(1234 + 100000 + i)
+        bw = int(rng.integers(90, 161))
+        bh = int(rng.integers(90, 161))
+        lens[i] = bw * bh
+    reps = (ALL_SUBJECTS + N_DISTINCT_CROPS - 1) // N_DISTINCT_CROPS
+    return np.tile(lens, reps)[:ALL_SUBJECTS]
+
+
+def shard_frames(synth, packing, a, b):
+    """Frames [a, b) of the 76,500-crop set as one packed batch (only the distinct crops the shard needs are generated)."""
+    ids = np.arange(a, b) % N_DISTINCT_CROPS
+    uniq = np.unique(ids)
+    made = {int(u): synth.synth_frame(100000 + int(u), "crop") for u in uniq}
+    lens = np.array([made[int(i)][1].size for i in ids], np.int64)
+    off = np.zeros(b - a + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    depth = np.empty(int(off[-1]), np.float32)
+    hdr = np.empty((b - a, 6), np.int32)
+    for k, i in enumerate(ids):
+        h, d = made[int(i)]
+        depth[off[k]:off[k + 1]] = d
+        hdr[k] = h
+    return packing.PackedFrames(depth, off, hdr)
+
+
+def config3_sharded(be, synth, shard, packing, rank, world, launches=3):
+    """This rank's pixel-balanced contiguous shard of the 76,500-crop set, resident, voxelized by `launches` launches
+    (HIP events).  Replaces the subject x gesture x frame loop of pre/read_MSRA.py:51,78,98-106.  Returns
+    (frames, pixels, seconds per launch)."""
+    lens = crop_lengths(synth)
+    a, b = shard.shard_bounds(ALL_SUBJECTS, world, weights=lens)[rank]
+    if be.name == "host-stub":
+        off = np.concatenate([[0], np.cumsum(lens[a:b])])
+        d = o = h = out = None
+    else:
+        pk = shard_frames(synth, packing, a, b)
+        assert np.array_equal(np.diff(pk.offsets), lens[a:b]), "crop_lengths() no longer mirrors synth.synth_frame()"
+        off = pk.offsets
+        d, o, h = be.upload(pk.depth, pk.offsets, pk.headers)
+        out = be.alloc_out(d, o, h)
+    be.launch(d, o, h, out)   # warm
+    e0, e1 = be.event(), be.event()
+    be.sync()
+    be.record(e0)
+    for _ in range(launches):
+        be.launch(d, o, h, out)
+    be.record(e1)
+    be.sync()
+    sec = be.elapsed_ms(e0, e1) / launches * 1e-3
+    del d, o, h, out
+    if be.name == "hip":
+        torch.cuda.empty_cache()
+    return b - a, int(off[-1]), sec
+
+
+def one_frame_report(pkg, synth, dev):
+    """BASELINE configs[0] the way pre/time_test.py:24-30 would report it: ONE MSRA-like frame through each
+    implementation.  (a) the cal_tsdf_cuda shim end to end — upload, one launch, volume back on the host, as
+    pre/tsdf_numba.py:133-158 does with four copies and two launches; (b) the same frame resident, one launch, result left
+    on the GPU; (c) the oracle (C port) on one core; (d) the reference's Python loop, quoted from the survey."""
+    import oracle
+    h, d = synth.synth_frame(100007, "crop")
+    s = {"header": h, "data": d}
+    for _ in range(5):
+        r = pkg.cal_tsdf_cuda(s)
+    assert r is not None
+    ts = []
+    for _ in range(60):
+        t0 = time.perf_counter()
+        pkg.cal_tsdf_cuda(s)
+        ts.append(time.perf_counter() - t0)
+    td = torch.from_numpy(d).to(dev)
+    to = torch.tensor([0, d.size], dtype=torch.int64, device=dev)
+    th = torch.from_numpy(h[None]).to(dev)
+    out = pkg.voxelize(td, to, th)
+    singles = []
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(60):
+        torch.cuda.synchronize()
+        a.record()
+        pkg.voxelize(td, to, th, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        singles.append(a.elapsed_time(b) * 1e-3)
+    off = np.array([0, d.size], np.int64)
+    oracle.voxelize(d, off, h[None], R=RES, n_threads=1)
+    tc = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        oracle.voxelize(d, off, h[None], R=RES, n_threads=1)
+        tc.append(time.perf_counter() - t0)
+    return {
+        "frame": f"one MSRA-like crop, bbox {int(h[4] - h[2])}x{int(h[5] - h[3])}, -> 32^3",
+        "cal_tsdf_cuda_shim_s": round(float(np.median(ts)), 6),
+        "cal_tsdf_cuda_shim_what": "handposeestimation-with-3d-cnns_amd.tsdf_numba.cal_tsdf_cuda(s): pageable H2D of the crop + "
+                                   "header, ONE launch, status check, 393 KB volume + max_l + mid_p back to numpy (host wall, median of 60)",
+        "voxelize_resident_s": round(float(np.median(singles)), 7),
+        "voxelize_resident_what": "the same frame already on the GPU, one launch, result left there (HIP events, median of 60)",
+        "oracle_one_core_s": round(float(np.median(tc)), 6),
+        "reference_python_loop_s": SURVEY_PY_LOOP["tsdf_f_crop_120x140_s_per_frame"],
+        "reference_python_loop_what": SURVEY_PY_LOOP["where"] + " (tsdf_for.tsdf_f, bbox 120x140)",
+        "what": "BASELINE configs[0] / pre/time_test.py:24-30 (the reference's only benchmark: one frame, CPU loop vs GPU path)",
+    }
+
+
 def extras(pkg, synth, dev, td, to, th, offsets):
     """The other BASELINE.json configs and the small-batch latencies, measured OUTSIDE the timed region (rank 0,
     N=1).  Every entry says what it ran; rates are device-resident unless the entry says "streamed"."""
+    import torch.utils.data as tdata
     ex = {}
+    ex["configs[0]_one_frame"] = one_frame_report(pkg, synth, dev)
     # ---- small batches: launch latency as a training step sees it (reference batch size: 16, 3D_CNN/train.py:36)
     lat = {}
     for n in (1, 16, 64, 256):
@@ -223,11 +572,11 @@ def extras(pkg, synth, dev, td, to, th, offsets):
              fn=lambda out: pkg.voxelize_aug(td, to, th, xf, res=64, out=out),
              note="BASELINE configs[4]: 1024 full frames -> 64^3 with the 3-D augmentation fused into the kernel")
     # MSRA-like crops: 2,048 distinct seeded crops, repeated to the stated counts
-    crops = [synth.synth_frame(100000 + i, "crop") for i in range(2048)]
+    crops = [synth.synth_frame(100000 + i, "crop") for i in range(N_DISTINCT_CROPS)]
     base = pkg.packing.pack_frames(crops)
 
     def tiled(n):
-        reps = (n + 2047) // 2048
+        reps = (n + N_DISTINCT_CROPS - 1) // N_DISTINCT_CROPS
         lens = np.tile(np.diff(base.offsets), reps)[:n]
         off = np.zeros(n + 1, np.int64)
         np.cumsum(lens, out=off[1:])
@@ -238,14 +587,6 @@ def extras(pkg, synth, dev, td, to, th, offsets):
     c1 = pk1.to_torch(dev)
     resident("crops_1024", c1[0], c1[1], c1[2], RES, 30, pk1.offsets, note="1024 MSRA-like crops (bbox side 90-160 px)")
     del c1
-    # configs[3], one-GPU form: all nine subjects' worth of crops resident, one launch
-    pk3 = tiled(76500)
-    c3 = pk3.to_torch(dev)
-    resident("configs[3]_one_gpu", c3[0], c3[1], c3[2], RES, 3, pk3.offsets,
-             note="BASELINE configs[3] on ONE GPU: 76,500 MSRA-like crops resident, one launch (the 8-GPU form is "
-                  "bench.py --gpus 8: frames shard by rank, no collective)")
-    del c3, pk3
-    torch.cuda.empty_cache()
     # configs[2]: one subject (8,500 crops) streamed from a pinned pack through VoxelLoader: H2D on a copy stream
     # overlapped with the voxelizer (PCIe-inclusive: never the headline value)
     pk2 = tiled(8500)
@@ -278,28 +619,57 @@ def extras(pkg, synth, dev, td, to, th, offsets):
             t0 = time.perf_counter()
             seen = 0
             for batch in ld:
-                seen += batch.tsdf.shape[0]
+                seen += batch[0].shape[0]
             torch.cuda.synchronize()
             r.append(seen / (time.perf_counter() - t0))
         return r
     rl = pkg.ResidentLoader(ds, batch_size=1024, device=dev, shuffle=True)
     r1024 = epochs(rl, 5)
     r16 = epochs(pkg.ResidentLoader(ds, batch_size=16, device=dev, shuffle=True), 3)
+    r16p = epochs(pkg.ResidentLoader(ds, batch_size=16, device=dev, shuffle=True, prefetch=64), 5)
     h1024 = epochs(pkg.VoxelLoader(ds, batch_size=1024, device=dev, shuffle=True, max_pixels=1024 * 160 * 160), 3)
     ex["configs[2]_resident_shuffled"] = {
         "frames": 8500, "resident_bytes": rl.resident_bytes(),
-        "batch_1024_crops_per_s": round(max(r1024[1:])), "batch_16_crops_per_s": round(max(r16[1:])),
+        "batch_1024_crops_per_s": round(max(r1024[1:])),
+        "batch_16_crops_per_s": round(max(r16p[1:])),
+        "batch_16_one_launch_per_batch_crops_per_s": round(max(r16[1:])),
         "host_fed_shuffled_batch_1024_crops_per_s": round(max(h1024[1:])),
         "what": "BASELINE configs[2] with the subject's pack resident in HBM (uploaded once; all of MSRA is 4.8 GB): shuffled "
-                "batches drawn by index on the device, labels included (dataset.ResidentLoader); and the same shuffled "
-                "batches through VoxelLoader, whose host gathers the crops before uploading them"}
+                "batches drawn by index on the device, labels included (dataset.ResidentLoader).  batch_16 = the reference's "
+                "training batch size (3D_CNN/train.py:36) with prefetch=64: the epoch's permutation is uploaded once, one "
+                "launch voxelizes 64 batches into a ring and the loader yields 16-frame views (bit-identical batches); "
+                "batch_16_one_launch_per_batch = prefetch=1; host_fed = the same shuffled batches through VoxelLoader, "
+                "whose host gathers the crops before uploading them"}
+    # the literal north-star consumer: the reference's own loader call (3D_CNN/train.py:36,86-91) over the on-the-fly dataset
+    mds = pkg.MSRA_Dataset.from_raw(ds, device=dev)
+    dl = tdata.DataLoader(mds, batch_size=16, shuffle=True)
+    rdl = epochs(dl, 4)
+
+    class _Floor(tdata.Dataset):      # what torch's loader machinery costs by itself: a dataset that does nothing
+        def __init__(self, n, item):
+            self.n, self.item = n, item
+        def __len__(self):
+            return self.n
+        def __getitems__(self, idx):
+            return self.item
+    first = next(iter(dl))
+    floor = epochs(tdata.DataLoader(_Floor(8500, [pkg.dataset.PreBatched(tuple(first))]), batch_size=16, shuffle=True), 3)
+    ex["north_star_dataloader_batch_16"] = {
+        "frames": 8500, "batch": 16, "crops_per_s": round(max(rdl[1:])),
+        "loader_floor_crops_per_s": round(max(floor[1:])),
+        "what": "DataLoader(MSRA_Dataset(...), batch_size=16, shuffle=True) — the reference's training loader call "
+                "(3D_CNN/train.py:36,86-91) — on the resident on-the-fly dataset: every batch is ONE launch issued from "
+                "__getitems__ (indices written to a pinned ring, outputs into a recycled ring, no per-item tensors, "
+                "collation by a registered type).  loader_floor = the same DataLoader call over a dataset whose __getitems__ "
+                "returns a constant: the cost of torch's sampler / fetcher / iterator machinery on this host, which bounds any "
+                "dataset behind that call"}
     ra = epochs(pkg.ResidentLoader(ds, batch_size=1024, device=dev, shuffle=True, res=64, augment=True), 3)
     ex["configs[4]_resident_shuffled_aug_r64"] = {
         "frames": 8500, "batch": 1024, "crops_per_s": round(max(ra[1:])),
         "what": "BASELINE configs[4] as a training loop would run it: the subject resident in HBM, shuffled batches by index, a "
                 "fresh reference-distribution 3-D augmentation per frame drawn on the host (numpy) and fused into the 64^3 "
                 "voxelizer, mapped joints + labels from the same launch (dataset.ResidentLoader(augment=True, res=64))"}
-    del rl
+    del rl, dl, mds
     # the same pipeline over four subjects' worth of frames: the 8,500-frame number above carries the fixed cost of
     # starting and draining a 9-batch epoch
     del loader, ds
@@ -341,95 +711,141 @@ def extras(pkg, synth, dev, td, to, th, offsets):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs / latency table (rank 0, N=1)")
+    ap.add_argument("--no-config3", action="store_true", help="skip configs[3]_sharded (every rank, every N)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the voxelizer has no CPU path")
+    dry = os.environ.get("TSDF_BENCH_DRYRUN") == "1"
     # TSDF_BENCH_REHEARSAL=1: dry run of the N>1 code path on a box with fewer GPUs than ranks (ranks share
-    # devices, the barrier / max-of-elapsed go over gloo instead of RCCL, the line says "rehearsal": true).
-    # Never set by the driver; a rehearsal number is not a measurement.
-    rehearsal = os.environ.get("TSDF_BENCH_REHEARSAL") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    # devices, the barrier / gathers go over gloo instead of RCCL, the line says "rehearsal": true).
+    rehearsal = os.environ.get("TSDF_BENCH_REHEARSAL") == "1" or dry
+
+    # ---- pin to the GPU's cores BEFORE the first GPU call (the runtime's helper threads inherit the mask); counting
+    # devices does not initialise the GPU on this image
+    ndev_hint = None if dry else (torch.cuda.device_count() or None)
+    affinity = pin_rank(local_rank, local_world, ndev_hint, rehearsal, os.environ.get("TSDF_BENCH_SYSFS", "/sys"))
+
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the voxelizer has no CPU path")
+    dev_index = 0 if dry else (local_rank % torch.cuda.device_count() if rehearsal else local_rank)
+    be = (HostStub if dry else HipBackend)(dev_index)
+    got_pci = be.pci()
+    if got_pci and affinity.get("pci"):
+        affinity["pci_matches_runtime"] = got_pci[:10] == affinity["pci"][:10]   # domain:bus:device
 
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
-        # launched by torch.distributed.run: RCCL for the start/stop barrier + max of elapsed only
+        # launched by torch.distributed.run: RCCL for rendezvous + small gathers only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=be.dev)
+    comm_dev = "cpu" if (rehearsal or dist is None) else be.dev
 
-    pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
+    def gather(vals):
+        """[world][len(vals)] float64 on every rank (N small numbers: host-side bookkeeping, not the data path)."""
+        t = torch.tensor([vals], dtype=torch.float64, device=comm_dev)
+        if dist is None:
+            return t.cpu().numpy()
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).cpu().numpy()
+
     synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+    shard = importlib.import_module("handposeestimation-with-3d-cnns_amd.shard")
+    packing = importlib.import_module("handposeestimation-with-3d-cnns_amd.packing")
 
-    # this rank's shard: frames [rank*1024, (rank+1)*1024) of the seeded synthetic set
-    depth, offsets, headers = synth.synth_batch(FRAMES_PER_GPU, "full", seed0=rank * FRAMES_PER_GPU)
-    td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, offsets, headers))
-    out = pkg.voxelize(td, to, th, res=RES)  # allocates the outputs once
-    torch.cuda.synchronize()
-    assert bool((out.status == 0).all())
+    # this rank's batch: frames [rank*1024, (rank+1)*1024) of the seeded synthetic set
+    if dry:
+        depth = np.zeros(FRAMES_PER_GPU * 76800, np.float32)
+        offsets = np.arange(FRAMES_PER_GPU + 1, dtype=np.int64) * 76800
+        headers = np.tile(np.array([320, 240, 0, 0, 320, 240], np.int32), (FRAMES_PER_GPU, 1))
+    else:
+        depth, offsets, headers = synth.synth_batch(FRAMES_PER_GPU, "full", seed0=rank * FRAMES_PER_GPU)
+    td, to, th = be.upload(depth, offsets, headers)
+    out = be.alloc_out(td, to, th)  # allocates the outputs once
 
     def collective_barrier():
-        dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
+        dist.barrier() if rehearsal else dist.barrier(device_ids=[dev_index])
 
-    node_barrier = NodeBarrier(dist, rank, world, collective_barrier) if dist is not None else None
+    node_barrier = NodeBarrier(dist, rank, world, collective_barrier, comm_dev) if dist is not None else None
 
     def barrier():
-        torch.cuda.synchronize()
+        be.sync()
         if dist is not None:
             node_barrier() if node_barrier.ok else collective_barrier()
-        torch.cuda.synchronize()
+        be.sync()
+
+    def step():
+        for _ in range(LAUNCHES_PER_STEP):
+            be.launch(td, to, th, out)
 
     for _ in range(args.warmup):
-        pkg.voxelize(td, to, th, res=RES, out=out)
-    # HIP events on the launch stream (torch's current stream): one pair around the K timed launches.
+        step()
+    # HIP events on the launch stream (torch's current stream): one pair around the K timed steps.
     # (Per-launch pairs were dropped from the timed region: every timestamped record costs ~3 us of
-    # stream idle time between two 150 us kernels; they are taken in a separate pass below.)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # stream idle time between two 135 us kernels; they are taken in a separate pass below.)
+    ev0, ev1 = be.event(), be.event()
 
     barrier()
     t0 = time.perf_counter()
-    ev0.record()
+    be.record(ev0)
     for k in range(args.steps):
-        pkg.voxelize(td, to, th, res=RES, out=out)
-    ev1.record()
+        step()
+    be.record(ev1)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    n_launch = args.steps * LAUNCHES_PER_STEP
+    my_event_ms = be.elapsed_ms(ev0, ev1)
+    timing = gather([elapsed, my_event_ms])          # [world][2]
+    elapsed_max = float(timing[:, 0].max())
 
     # diagnostic pass (outside the timed region): per-launch event pairs -> spread of single launches
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 50))]
+    ev = [(be.event(), be.event()) for _ in range(50)]
     for a, b in ev:
-        a.record()
-        pkg.voxelize(td, to, th, res=RES, out=out)
-        b.record()
-    torch.cuda.synchronize()
-
-    kern_ms = np.array([a.elapsed_time(b) for a, b in ev])
-    launch_ms = ev0.elapsed_time(ev1) / args.steps  # mean launch-to-launch time over the timed region
+        be.record(a)
+        be.launch(td, to, th, out)
+        be.record(b)
+    be.sync()
+    kern_ms = np.array([be.elapsed_ms(a, b) for a, b in ev])
+    launch_ms = my_event_ms / n_launch  # mean launch-to-launch time over the timed region
     abytes = algorithmic_bytes(offsets, FRAMES_PER_GPU, RES)
 
+    # ---- BASELINE configs[3]: every rank voxelizes its shard of the 76,500-crop set (no collective on the data path)
+    c3 = None
+    if not args.no_config3:
+        del out
+        out = None
+        f3, px3, s3 = config3_sharded(be, synth, shard, packing, rank, world)
+        g3 = gather([f3, px3, s3])                   # [world][3]
+        fr, px, sec = g3[:, 0], g3[:, 1], g3[:, 2]
+        c3 = {
+            "frames": int(fr.sum()), "per_rank_frames": [int(v) for v in fr],
+            "per_rank_pixels": [int(v) for v in px],
+            "per_rank_ms_per_launch": [round(float(v) * 1e3, 3) for v in sec],
+            "per_rank_fps": [round(float(f / s)) for f, s in zip(fr, sec)],
+            "aggregate_fps": round(float(fr.sum() / sec.max())),
+            "imbalance": round(float(sec.max() / sec.mean()), 4),
+            "what": "BASELINE configs[3]: all nine subjects' worth of MSRA-like crops (76,500), contiguous shards balanced by "
+                    "pixels (shard.shard_bounds), every rank voxelizes its own shard resident in its GPU's HBM in one launch "
+                    "(HIP events, mean of 3); aggregate = all frames / the slowest rank's launch; imbalance = slowest / mean"}
+
     if rank == 0:
-        total_frames = world * FRAMES_PER_GPU * args.steps
+        total_frames = world * FRAMES_PER_GPU * n_launch
         mean_ms = float(launch_ms)
         achieved = abytes / (mean_ms * 1e-3) / 1e9
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate FETCH_SIZE and
@@ -443,12 +859,12 @@ def main():
                 traffic = None
         line = {
             "metric": "depth frames/sec to 32^3 TSDF",
-            "value": round(total_frames / elapsed, 1),
+            "value": round(total_frames / elapsed_max, 1),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -457,9 +873,17 @@ def main():
             "barrier": (("node (/dev/shm)" if node_barrier.ok else "collective") if dist is not None else "none (one process)"),
             "config": {
                 "workload": "BASELINE configs[1]: batch 1024 synthetic 320x240 full-frame depth crops -> 32^3 "
-                            "3-channel TSDF per GPU, inputs resident in HBM, one fused launch per step",
-                "frames_per_gpu": FRAMES_PER_GPU, "res": RES, "layout": "czyx",
+                            "3-channel TSDF per GPU and launch, inputs resident in HBM; one step = "
+                            f"{LAUNCHES_PER_STEP} back-to-back fused launches of that batch",
+                "frames_per_launch": FRAMES_PER_LAUNCH, "launches_per_step": LAUNCHES_PER_STEP,
+                "frames_per_gpu_per_step": FRAMES_PER_LAUNCH * LAUNCHES_PER_STEP, "res": RES, "layout": "czyx",
                 "parallelism": f"frame-sharded x{world}, no collective",
+            },
+            "per_rank": {
+                "ms_per_step_events": [round(float(v) / args.steps, 4) for v in timing[:, 1]],
+                "ms_per_step_host_wall": [round(float(v) / args.steps * 1e3, 4) for v in timing[:, 0]],
+                "frames_per_s_events": [round(FRAMES_PER_GPU * n_launch / (float(v) * 1e-3)) for v in timing[:, 1]],
+                "what": "every rank's own timed region: HIP events on its launch stream, and host wall between the two barriers",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -476,23 +900,41 @@ def main():
         }
         if rehearsal:
             line["rehearsal"] = True
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            line["dry_run"] = "TSDF_BENCH_DRYRUN=1: host stub, no GPU work — orchestration test only, the numbers mean nothing"
+        ex = {}
+        if c3 is not None:
+            ex["configs[3]_sharded"] = c3
+        if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(depth, offsets, headers)
         if world == 1 and not args.no_extras and not rehearsal:
-            line["extras"] = extras(pkg, synth, dev, td, to, th, offsets)
+            if out is None:
+                out = be.alloc_out(td, to, th)
+            ex.update(extras(be.pkg, synth, be.dev, td, to, th, offsets))
             sc = stream_ceilings()
             if sc:
-                line["extras"]["stream_ceilings"] = sc
+                ex["stream_ceilings"] = sc
                 cp = max(sc.get("copy_nt", 0.0), sc.get("copy", 0.0))
                 if cp > 0:   # interleaved reads and writes are the fair comparison for this kernel
                     line["roofline"]["frac_of_copy_stream_this_box"] = round(line["roofline"]["achieved"] / cp, 4)
                     if traffic:
                         line["roofline"]["traffic_rate_GBps"] = round(traffic / (mean_ms * 1e-3) / 1e9, 1)
                         line["roofline"]["traffic_rate_over_copy_stream"] = round(traffic / (mean_ms * 1e-3) / 1e9 / cp, 4)
+        if ex:
+            line["extras"] = ex
+
+    # every rank's CPU mask, on rank 0's line (small python objects: bookkeeping, not the data path)
+    if dist is not None:
+        masks = [None] * world
+        dist.all_gather_object(masks, affinity)
+    else:
+        masks = [affinity]
+    if rank == 0:
+        line["per_rank"]["affinity"] = masks
         print(json.dumps(line), flush=True)
 
     if dist is not None:
-        dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
+        collective_barrier()
         dist.destroy_process_group()
 
 

@@ -10,8 +10,23 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# TSDF_HIP_LIB may point at another build of the same ABI (e.g. the stamps diagnostic build)
-LIB_PATH = os.environ.get("TSDF_HIP_LIB") or os.path.join(_HERE, "libtsdf_hip.so")
+_DEFAULT_LIB = os.path.join(_HERE, "libtsdf_hip.so")
+
+
+def _lib_path() -> str:
+    """The product binary.  TSDF_HIP_LIB may name another build of the same ABI (diagnostic variants live in
+    <repo>/build/), but only together with TSDF_ALLOW_LIB_OVERRIDE=1: a stale variable must not silently swap the
+    library the tests and the bench believe they are measuring."""
+    over = os.environ.get("TSDF_HIP_LIB")
+    if not over or os.path.abspath(over) == _DEFAULT_LIB:
+        return _DEFAULT_LIB
+    if os.environ.get("TSDF_ALLOW_LIB_OVERRIDE") != "1":
+        raise ImportError(f"TSDF_HIP_LIB={over} asks for a library other than {_DEFAULT_LIB}; set "
+                          "TSDF_ALLOW_LIB_OVERRIDE=1 as well if that is intended (experiments only)")
+    return over
+
+
+LIB_PATH = _lib_path()
 
 TSDF_LAYOUT_CZYX = 0
 TSDF_LAYOUT_CXYZ = 1
@@ -51,7 +66,7 @@ class TsdfLabels(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -101,6 +116,9 @@ def load():
                                                 cam_p, ctypes.c_int, vp, vp, vp, vp, vp, vp, lab_p]
     L.tsdf_host_gather_frames.restype = ctypes.c_int
     L.tsdf_host_gather_frames.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int]
+    L.tsdf_host_gather_frames_n.restype = ctypes.c_int
+    L.tsdf_host_gather_frames_n.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, vp,
+                                            ctypes.c_int]
     L.tsdf_normalize_joints_hip.restype = ctypes.c_int
     L.tsdf_normalize_joints_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.tsdf_denormalize_joints_hip.restype = ctypes.c_int

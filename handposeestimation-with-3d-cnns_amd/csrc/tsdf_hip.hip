@@ -61,12 +61,23 @@
 namespace {
 
 constexpr int kWG = 1024;               // threads per workgroup (16 wave64; needs <= 128 VGPRs)
-#ifndef TSDF_GROUPS
-#define TSDF_GROUPS 2
+// Groups per workgroup: each walks its own frames (see the kernel).  A template parameter of the fused kernel, chosen
+// per resolution (groups_for): two 512-thread groups at 32^3 — one's row stream hides behind the other's voxel pass —,
+// ONE 1024-thread group from 48^3 upwards, where the voxel pass is 8x the row stream and what counts is that a CU
+// writes each channel plane of its volume as one sequential run (paired A/B on 1024 full frames -> 64^3: plain -3.7 %,
+// augmented -4.3 %; at 32^3 one group is +8 % on full frames, +13 % on crops).  -DTSDF_GROUPS=g forces one value
+// everywhere (experiments).  The names below are the defaults of code outside the fused kernel (stamps; the split
+// kernel's LDS layout); inside it they are shadowed by the instantiation's own values.
+#ifdef TSDF_GROUPS
+constexpr int kGroupsForced = TSDF_GROUPS;
+#else
+constexpr int kGroupsForced = 0;
 #endif
-constexpr int kGroups = TSDF_GROUPS;    // half-workgroups: each walks its own frames, see the kernel
+constexpr int kGroups = kGroupsForced ? kGroupsForced : 2;
+constexpr int kMaxGroups = kGroups > 2 ? kGroups : 2;
 constexpr int kGW = kWG / kGroups;      // threads per group
-constexpr int kGWaves = kGW / 64;       // waves per group
+[[maybe_unused]] constexpr int kGWaves = kGW / 64;  // waves per group
+constexpr int groups_for(int R) { return kGroupsForced ? kGroupsForced : (R >= 48 ? 1 : 2); }
 constexpr int kMaxR = 128;
 constexpr int kTabR = 32;               // projection tables for R <= kTabR (2 + 4 KiB per group)
 constexpr int kRedStride = 12;
@@ -1017,67 +1028,90 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
 }
 
 // Phase 2 of the augmented form (oracle/tsdf_oracle.c::tsdf_oracle_voxels_aug): the voxel centre v'
-// lives in the augmented frame, v = T^-1(v') is projected, the surface point w is mapped forward and the
-// distances are taken between v' and T(w).  The projection no longer factorises, so there are no pixel
-// tables and q = -F / v_z is one true division per voxel; what does factorise is the inverse map: its
-// three products per row, A_i0*v'_x, A_i1*v'_y, A_i2*v'_z, depend on one grid index each and are
-// tabulated per frame (atab, 9*R doubles), leaving (a + b) + (c + d) — the oracle's exact rounding order.
-// atab layout: [axis][index][row] = fl(inv[4*row + axis] * (ori_axis + index*voxel_len)), the z entries + b_row.
+// lives in the augmented frame, v = T^-1(v') is projected and the pixel gathered as in the plain pass; the
+// distances are those between v' and T(w), w the pixel's surface point.  The projection no longer factorises,
+// so there are no pixel tables and q = -F / v_z is one true division per voxel; what does factorise is the
+// inverse map: its three products per row, A_i0*v'_x, A_i1*v'_y, A_i2*v'_z, depend on one grid index each and
+// are tabulated per frame (atab), leaving (a + b) + (c + d) — the oracle's exact rounding order.
+// The distances never form w or T(w) (round 2 did: ~21 float64 operations per voxel before the first test).
+// For an affine T,  v'_i - w'_i = (v'_i - b_i) + pd * c_i  with  c_i = fma(g_i0, dxi, fma(g_i1, dyi, A_i2)),
+// g_i0 = -(A_i0 / F), g_i1 = A_i1 / F per frame, dxi = pix_x - cx, dyi = pix_y - cy: three fma for the z
+// component that decides everything a far or rejected voxel needs (|u_z| > trunc_dis -> (+-1,+-1,+-1), sign of
+// u_z), and the x / y components only in wave tiles that hold a near voxel.  The contract (include/tsdf.h,
+// restated operation by operation in the oracle) is written in exactly this form.
+// atab layout: [axis][index][4] = { fl(inv[4*row + axis] * (ori_axis + index*voxel_len)) for row 0..2 — the z
+// entries + b_row —, (ori_axis + index*voxel_len) - fwd_b[axis] }.
+__device__ __forceinline__ double uniform64(double v) {  // a wave-uniform float64 -> scalar registers
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                            const double *xf, const Tabs &tb, const SrcP src,
                                            const GlobalOut out, const int tid, const int sb, const int se) {
   if (se <= sb) return;  // (uniform) nothing to do; the end-slice lookups below assume one slice at least
-  const double vl = (double)g.voxel_len;
-  const double ox = (double)g.ori[0], oy = (double)g.ori[1], oz = (double)g.ori[2];
   const double *fwd = xf;
-  const LdsCD tabx = tb.atab, taby = tb.atab + 3 * R, tabz = tb.atab + 6 * R;
+  const LdsCD tabx = tb.atab, taby = tb.atab + 4 * R, tabz = tb.atab + 8 * R;
   const int R4 = R / 4;
   const int G = R * R4;
   const int64_t R3 = (int64_t)R * R * R;
-  int g0, gstep, s0, sstep;
+  // per-frame constants of the distance terms, kept in scalar registers
+  double g0[3], g1[3], a2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g0[i] = uniform64(-(fwd[4 * i] * cam.inv_focal));
+    g1[i] = uniform64(fwd[4 * i + 1] * cam.inv_focal);
+    a2[i] = fwd[4 * i + 2];
+  }
+  // |u_z| beyond this is beyond the truncation distance whatever x and y are: t_z = u_z * it with it = fl(1/trunc)
+  // is then > 1 + 2^-31 after both roundings, so dist^2 > 1 (the gate may only err towards "look closer")
+  const double tgate = uniform64((double)g.trunc * (1.0 + 0x1p-30));
+  int g0i, gstep, s0, sstep;
   if (G <= T && (T % G) == 0) {
-    g0 = tid % G;
+    g0i = tid % G;
     gstep = G;
     s0 = tid / G;
     sstep = T / G;
   } else {
-    g0 = tid;
+    g0i = tid;
     gstep = T;
     s0 = 0;
     sstep = 1;
   }
-  for (int gi = g0; gi < G; gi += gstep) {
+  for (int gi = g0i; gi < G; gi += gstep) {
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
-    const double vpy = oy + (double)y * vl;
-    const double vpy_it = vpy * vk.it;  // centre coordinates pre-scaled by 1/trunc_dis, as in the plain pass
-    const double ty0 = taby[3 * y], ty1 = taby[3 * y + 1], ty2 = taby[3 * y + 2];
+    const double ty0 = taby[4 * y], ty1 = taby[4 * y + 1], ty2 = taby[4 * y + 2];
+    const double vby = taby[4 * y + 3];   // v'_y - b_y
     // The inverse map is (A_i0 x' + A_i1 y') + (A_i2 z' + b_i), every product and sum rounded separately (the
     // oracle's affine3).  Both brackets depend on grid indices only: the z table holds (A_i2 z' + b_i), and the
     // bracket that does not change from slice to slice stays in registers — LAYOUT 0 (x, y fixed per lane) keeps
     // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps the z bracket — so a voxel costs ONE add
-    // per row of the map.
-    double pre[4][3];
+    // per row of the map.  The same goes for v' - b of the distance terms: the fixed axes' live in registers
+    // (vbf), the slice's comes from its table entry.
+    double pre[4][3], vbf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (LAYOUT == 0) {
-        const LdsCD tx = tabx + 3 * (f4i + j);
+        const LdsCD tx = tabx + 4 * (f4i + j);
         pre[j][0] = tx[0] + ty0;
         pre[j][1] = tx[1] + ty1;
         pre[j][2] = tx[2] + ty2;
+        vbf[j] = tx[3];                    // v'_x - b_x
       } else {
-        const LdsCD tzp = tabz + 3 * (f4i + j);
+        const LdsCD tzp = tabz + 4 * (f4i + j);
         pre[j][0] = tzp[0];
         pre[j][1] = tzp[1];
         pre[j][2] = tzp[2];
+        vbf[j] = tzp[3];                   // v'_z - b_z
       }
     }
     // Which division (neg_focal_over): v_z of a lane's voxel is fl(pre + slice term), monotone in the slice index
     // (every rounding is), so its two end slices bound it; same sign and mid-range at both ends -> mid-range throughout.
     bool mild = mid_range(cam.focal, 0x1p-100, 0x1p100);
     {
-      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 3 * sb, thi = (LAYOUT == 0 ? tabz : tabx) + 3 * (se - 1);
+      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 4 * sb, thi = (LAYOUT == 0 ? tabz : tabx) + 4 * (se - 1);
       const double s_lo = LAYOUT == 0 ? tlo[2] : tlo[2] + ty2, s_hi = LAYOUT == 0 ? thi[2] : thi[2] + ty2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1092,25 +1126,22 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
       int ex[4], ry[4];
       float pd[4];
       bool ok[4];
-      double vpx[4], vpz[4], az[4], tz[4], q2[4];
-      bool any_near = false;
-      double sl0, sl1, sl2;  // the slice's own terms (wave-uniform)
+      double sl0, sl1, sl2, vbs;  // the slice's own terms (wave-uniform)
       if constexpr (LAYOUT == 0) {
-        const LdsCD tzp = tabz + 3 * sl;
+        const LdsCD tzp = tabz + 4 * sl;
         sl0 = tzp[0];
         sl1 = tzp[1];
         sl2 = tzp[2];
+        vbs = tzp[3];                      // v'_z - b_z
       } else {
-        const LdsCD tx = tabx + 3 * sl;
+        const LdsCD tx = tabx + 4 * sl;
         sl0 = tx[0] + ty0;
         sl1 = tx[1] + ty1;
         sl2 = tx[2] + ty2;
+        vbs = tx[3];                       // v'_x - b_x
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int x = LAYOUT == 0 ? f4i + j : sl, z = LAYOUT == 0 ? sl : f4i + j;
-        vpx[j] = ox + (double)x * vl;
-        vpz[j] = oz + (double)z * vl;
         const double vx = pre[j][0] + sl0;   // v = T^-1(v') = (A_i0 x' + A_i1 y') + (A_i2 z' + b_i)
         const double vy = pre[j][1] + sl1;
         const double vz = pre[j][2] + sl2;
@@ -1122,22 +1153,20 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
         ok[j] = inb & (__builtin_fabsf(pd[j]) >= vk.eps);                        // :40
       }
       // ---- z component first: a wave whose voxels are all beyond the truncation distance along z' alone
-      // needs nothing else (dist >= |tz| > 1 -> (1,1,1)); one whose voxels are all rejected needs nothing ----
-      double wx[4], wy[4];
-      float sv[4];  // 0 for a rejected voxel, else the sign of :65-68 as +-1: the whole answer unless near
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sv[j] = 0.0f;
+      // needs nothing else (dist >= |t_z| > 1 -> (1,1,1)); one whose voxels are all rejected needs nothing ----
       f4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
       if (__any(ok[0] | ok[1] | ok[2] | ok[3])) {
+        double dxi[4], dyi[4], uz[4];
+        float sv[4];  // 0 for a rejected voxel, else the sign of :65-68 as +-1: the whole answer unless near
+        bool any_near = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          q2[j] = div_by_focal((double)pd[j], cam);                                // :43
-          wx[j] = ((double)ex[j] + vk.dxc) * q2[j];                                // :44 (pix_x - cx, exact)
-          wy[j] = -((double)ry[j] + vk.dyc) * q2[j];                               // :45
-          az[j] = affine_row(fwd + 8, wx[j], wy[j], -(double)pd[j]);               // w'_z, w_z = -pd :46
-          tz[j] = __builtin_fma(-az[j], vk.it, vpz[j] * vk.it);                    // :49 (v'_z - w'_z)/trunc
-          any_near |= ok[j] & (__builtin_fabs(tz[j]) <= 1.0);
-          sv[j] = ok[j] ? (az[j] > vpz[j] ? -1.0f : 1.0f) : 0.0f;                  // w'_z > v'_z  :65
+          dxi[j] = (double)ex[j] + vk.dxc;                                         // pix_x - cx  :44 (exact)
+          dyi[j] = (double)ry[j] + vk.dyc;                                         // pix_y - cy  :45
+          const double cz = __builtin_fma(g0[2], dxi[j], __builtin_fma(g1[2], dyi[j], a2[2]));
+          uz[j] = __builtin_fma((double)pd[j], cz, LAYOUT == 0 ? vbs : vbf[j]);    // v'_z - w'_z  :46,:49
+          any_near |= ok[j] & (__builtin_fabs(uz[j]) <= tgate);
+          sv[j] = ok[j] ? (uz[j] < 0.0 ? -1.0f : 1.0f) : 0.0f;                     // w'_z > v'_z  :65
         }
         o0 = f4{sv[0], sv[1], sv[2], sv[3]};
         o1 = o0;
@@ -1147,16 +1176,17 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
                 *p2 = reinterpret_cast<float *>(&o2);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const double wz = -(double)pd[j];
-            const double ax = affine_row(fwd + 0, wx[j], wy[j], wz);
-            const double ay = affine_row(fwd + 4, wx[j], wy[j], wz);
-            const double tx = __builtin_fma(-ax, vk.it, vpx[j] * vk.it);           // :47
-            const double ty = __builtin_fma(-ay, vk.it, vpy_it);                   // :48
-            const double s2 = __builtin_fma(tz[j], tz[j], __builtin_fma(ty, ty, tx * tx));
+            const double pd64 = (double)pd[j];
+            const double cxx = __builtin_fma(g0[0], dxi[j], __builtin_fma(g1[0], dyi[j], a2[0]));
+            const double cyy = __builtin_fma(g0[1], dxi[j], __builtin_fma(g1[1], dyi[j], a2[1]));
+            const double ux = __builtin_fma(pd64, cxx, LAYOUT == 0 ? vbf[j] : vbs);  // v'_x - w'_x  :47
+            const double uy = __builtin_fma(pd64, cyy, vby);                         // v'_y - w'_y  :48
+            const double tx = ux * vk.it, ty = uy * vk.it, tz = uz[j] * vk.it;
+            const double s2 = __builtin_fma(tz, tz, __builtin_fma(ty, ty, tx * tx));
             const bool nearv = s2 <= 1.0;                                          // :54
             const float m0 = vminabs((float)tx, 1.0f);
             const float m1 = vminabs((float)ty, 1.0f);
-            const float m2 = vminabs((float)tz[j], 1.0f);
+            const float m2 = vminabs((float)tz, 1.0f);
             p0[j] = nearv ? __fmul_rn(m0, sv[j]) : sv[j];                          // exact: sv is +-1 or 0
             p1[j] = nearv ? __fmul_rn(m1, sv[j]) : sv[j];
             p2[j] = nearv ? __fmul_rn(m2, sv[j]) : sv[j];
@@ -1255,13 +1285,13 @@ struct HelpReq {
 };
 
 struct GroupCtl {
-  int bar[kGroups];
+  int bar[kMaxGroups];
   int local_next;         // CU-local work queue (launches without a global queue word)
   int lock;               // TSDF_P2_LOCK builds: one group at a time between the extents barrier and the end of phase 2
   int help_for;           // 0: none; g+1: group g is asked to help with the frame in `help`
-  int idle[kGroups];
-  int cap_fail[kGroups];  // a row of the group's current frame did not fit the pool
-  FrameHdr hdr[kGroups];  // mailbox: the group's first wave fetches the next frame for the others
+  int idle[kMaxGroups];
+  int cap_fail[kMaxGroups];  // a row of the group's current frame did not fit the pool
+  FrameHdr hdr[kMaxGroups];  // mailbox: the group's first wave fetches the next frame for the others
   HelpReq help;
 };
 
@@ -1289,8 +1319,9 @@ __device__ __forceinline__ void lds_store(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+template <int GWAVES>
 __device__ __forceinline__ void group_barrier(int *cnt, int &target) {
-  target += kGWaves;
+  target += GWAVES;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) {
     __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1303,7 +1334,7 @@ __device__ __forceinline__ void group_barrier(int *cnt, int &target) {
 // ---- the workgroup's LDS: everything the CU has --------------------------------------------------
 // Per group: projection tables, z table, (AUG) inverse-map products, row table, reduction scratch.
 // Shared: control block and the row-span pool, which gets all the rest.
-template <int RT, bool AUG>
+template <int RT, bool AUG, int GROUPS = 2>
 struct Lds {
   static constexpr int kZ = RT ? RT : kMaxR;
   static constexpr bool kHasTab = !AUG && (RT == 0 || RT <= kTabR);
@@ -1313,17 +1344,17 @@ struct Lds {
     alignas(16) int pxtab[kTabN];
     alignas(16) unsigned char pyrow[kTabN];
     alignas(16) ZEntry ztab[kZ];
-    alignas(16) double atab[AUG ? 9 * kZ : 2];
+    alignas(16) double atab[AUG ? 12 * kZ : 2];
     alignas(16) unsigned rowtab[kMaxRows];
     alignas(16) float red[16 * kRedStride];  // 16 waves in the split kernel
   };
-  static constexpr int kFixed = kGroups * (int)sizeof(PerGroup) + (int)sizeof(GroupCtl) + 64;
+  static constexpr int kFixed = GROUPS * (int)sizeof(PerGroup) + (int)sizeof(GroupCtl) + 64;
   static constexpr int kPoolFloats = ((kLdsBytes - kFixed) / 16) * 4;
   static constexpr int kPoolUnits = kPoolFloats / 4;
   static_assert(kPoolUnits < 16384, "pool offsets are 14 bits of 4-float units");
   struct Block {
     alignas(16) float pool[kPoolFloats];
-    PerGroup pg[kGroups];
+    PerGroup pg[GROUPS];
     alignas(16) GroupCtl ctl;
   };
   static_assert(sizeof(Block) <= kLdsBytes, "LDS layout exceeds the CU");
@@ -1539,13 +1570,18 @@ __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &c
     pg.ztab[vt] = ze;
   }
   if constexpr (AUG) {
-    // products of the inverse map, one per (axis, index, row): see phase2_aug
+    // per (axis, index): the three products of the inverse map and v' - b of the forward map: see phase2_aug
     const double *inv = xf + 12;
-    for (int e = vt; e < 9 * R; e += T) {
-      const int axis = e / (3 * R), rem = e - axis * 3 * R, i = rem / 3, row = rem - 3 * i;
+    for (int e = vt; e < 12 * R; e += T) {
+      const int axis = e / (4 * R), rem = e - axis * 4 * R, i = rem >> 2, row = rem & 3;
       const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
-      const double prod = inv[4 * row + axis] * (o_a + (double)i * vl);
-      pg.atab[e] = axis == 2 ? prod + inv[4 * row + 3] : prod;   // the z entries carry the translation
+      const double vp = o_a + (double)i * vl;                    // :26-28
+      if (row < 3) {
+        const double prod = inv[4 * row + axis] * vp;
+        pg.atab[e] = axis == 2 ? prod + inv[4 * row + 3] : prod;   // the z entries carry the translation
+      } else {
+        pg.atab[e] = vp - xf[4 * axis + 3];
+      }
     }
   }
   if (use_tab) {
@@ -1585,12 +1621,13 @@ __device__ unsigned int g_queue[kQueueSlots];
 // (The read-only inputs are passed as separate __restrict__ parameters as well as inside KArgs: alias information
 // does not survive a by-value struct, and without it the compiler may not use scalar loads for wave-uniform
 // reads — the per-frame transform of the augmented form became 700 vector loads in the unrolled row pass.)
-template <int RT, int LAYOUT, bool AUG, bool DBG>
+template <int RT, int LAYOUT, bool AUG, bool DBG, int GROUPS>
 __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const float *__restrict__ in_depth,
                                                          const int64_t *__restrict__ in_offsets,
                                                          const int32_t *__restrict__ in_headers,
                                                          const double *__restrict__ in_xforms) {
-  using L = Lds<RT, AUG>;
+  constexpr int kGroups = GROUPS, kGW = kWG / GROUPS, kGWaves = kGW / 64;  // (shadow the file-scope defaults)
+  using L = Lds<RT, AUG, GROUPS>;
   __shared__ typename L::Block lds;
 
   const int R = RT ? RT : a.R;
@@ -1610,7 +1647,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
   }
   __syncthreads();  // the only workgroup-wide barrier
   int bar_target = 0;
-  auto gsync = [&]() { group_barrier(&ctl.bar[group], bar_target); };
+  auto gsync = [&]() { group_barrier<kGWaves>(&ctl.bar[group], bar_target); };
 
   Capture cap;
   cap.pool = (LdsF)lds.pool;
@@ -1780,18 +1817,20 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         pm.dc = vk.px0 - f.l;
         pm.dr = vk.py0 - f.t;
         auto run2 = [&](auto src) {
-          if (__builtin_expect(helped, 0)) {
-            if constexpr (AUG) {
-              phase2_aug<LAYOUT, 2 * kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
-            } else {
-              phase2<LAYOUT, 2 * kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
+          if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
+            if (__builtin_expect(helped, 0)) {
+              if constexpr (AUG) {
+                phase2_aug<LAYOUT, 2 * kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
+              } else {
+                phase2<LAYOUT, 2 * kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
+              }
+              return;
             }
+          }
+          if constexpr (AUG) {
+            phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
           } else {
-            if constexpr (AUG) {
-              phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
-            } else {
-              phase2<LAYOUT, kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
-            }
+            phase2<LAYOUT, kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
           }
         };
         if (mode == kFillRect) {
@@ -2076,21 +2115,21 @@ const tsdf_cam kDefaultCam = {241.42, 160.0, 120.0, 1.0f, 3.0f};
 
 // CU count of the current device (cached per device id; a racing first call computes the same value)
 int num_cus() {
-  static int cached[64] = {0};
+  static std::atomic<int> cached[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cached[dev] == 0) {
-    int v = 0;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cached[dev] = v;
+    cached[dev].store(v, std::memory_order_relaxed);
   }
-  return cached[dev];
+  return v;
 }
 
 // The code object holds gfx950 kernels only: any other device is "no usable device", not a launch error.
 // (Cached per device id; a racing first call computes the same value.)
 int check_device(int *dev_out) {
-  static int arch_state[64] = {0};  // 0 unknown, 1 gfx950, -1 something else
+  static std::atomic<int> arch_state[64];  // 0 unknown, 1 gfx950, -1 something else
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
@@ -2098,15 +2137,17 @@ int check_device(int *dev_out) {
   }
   *dev_out = dev;
   if (dev < 0 || dev >= 64) return TSDF_OK;  // beyond the cache: let the launch decide
-  if (arch_state[dev] == 0) {
+  int st = arch_state[dev].load(std::memory_order_relaxed);
+  if (st == 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
       (void)hipGetLastError();
       return TSDF_ERR_NO_DEVICE;
     }
-    arch_state[dev] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : -1;
+    st = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : -1;
+    arch_state[dev].store(st, std::memory_order_relaxed);
   }
-  return arch_state[dev] == 1 ? TSDF_OK : TSDF_ERR_NO_DEVICE;
+  return st == 1 ? TSDF_OK : TSDF_ERR_NO_DEVICE;
 }
 
 // ---- work-queue words: one per (device, stream) ------------------------------------------------------
@@ -2269,13 +2310,24 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
       return hipGetLastError();
     }
   }
-  // persistent: one workgroup per CU; with fewer than kGroups frames per CU the later groups idle or help
+  // persistent: one workgroup per CU; with fewer frames per CU than groups the later groups idle or help
   const int grid = a.n < cus ? a.n : cus;
   a.split = 0;
   a.per = a.R;
-  a.queue = a.n > grid * kGroups ? queue_word(dev, s) : nullptr;  // no dynamic frames: no word needed
-  hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
-                     a.headers, a.xforms);
+  auto fused = [&](auto groups_tag) {
+    constexpr int G = decltype(groups_tag)::value;
+    a.queue = a.n > grid * G ? queue_word(dev, s) : nullptr;  // no dynamic frames: no word needed
+    hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG, G>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
+                       a.headers, a.xforms);
+  };
+  if constexpr (RT != 0) {
+    fused(std::integral_constant<int, groups_for(RT)>{});
+  } else if constexpr (groups_for(32) == groups_for(64)) {
+    fused(std::integral_constant<int, groups_for(32)>{});
+  } else {   // any other resolution: the instantiation is generic in R, the group count follows the resolution
+    if (groups_for(a.R) == groups_for(64)) fused(std::integral_constant<int, groups_for(64)>{});
+    else fused(std::integral_constant<int, groups_for(32)>{});
+  }
   return hipGetLastError();
 }
 
@@ -2394,26 +2446,27 @@ int tsdf_version(void) { return TSDF_ABI_VERSION; }
 
 // Host-side helper of the loaders (no GPU involved): frames index[0..n) of a packed host buffer copied back to back into
 // dst (e.g. a page-locked staging buffer), dst_offsets[n+1] filled in.  `threads` workers split the bytes evenly.
-int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_t n_src, const int64_t *index, int64_t n,
-                            float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads) {
+// src_len < 0: unknown (the v4 entry).
+static int host_gather(const float *src, int64_t src_len, const int64_t *src_offsets, int64_t n_src, const int64_t *index,
+                       int64_t n, float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads) {
   if (n < 0 || n_src < 0 || (n > 0 && (!src || !src_offsets || !index || !dst || !dst_offsets))) return TSDF_ERR_INVALID_ARG;
   if (!dst_offsets) return n == 0 ? TSDF_OK : TSDF_ERR_INVALID_ARG;
   dst_offsets[0] = 0;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t f = index[i];
     if (f < 0 || f >= n_src) return TSDF_ERR_INVALID_ARG;
-    const int64_t len = src_offsets[f + 1] - src_offsets[f];
-    if (len < 0) return TSDF_ERR_INVALID_ARG;
-    dst_offsets[i + 1] = dst_offsets[i] + len;
+    const int64_t b = src_offsets[f], e = src_offsets[f + 1];
+    if (b < 0 || e < b || (src_len >= 0 && e > src_len)) return TSDF_ERR_INVALID_ARG;  // a damaged pack: nothing is read
+    dst_offsets[i + 1] = dst_offsets[i] + (e - b);
   }
   const int64_t total = dst_offsets[n];
   if (total > dst_capacity) return TSDF_ERR_INVALID_ARG;
   if (threads < 1) threads = 1;
   if (threads > 64) threads = 64;
   if (total * 4 < (1 << 20)) threads = 1;  // under a megabyte: starting threads costs more than the copy
-  auto work = [&](int t) {
+  auto work = [&](int t, int of) {
     // frames whose first element falls into this worker's share of the elements
-    const int64_t lo = total * t / threads, hi = total * (t + 1) / threads;
+    const int64_t lo = total * t / of, hi = total * (t + 1) / of;
     for (int64_t i = 0; i < n; ++i) {
       const int64_t a = dst_offsets[i];
       if (a < lo) continue;
@@ -2422,14 +2475,33 @@ int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_
     }
   };
   if (threads == 1) {
-    work(0);
-  } else {
-    std::thread pool[64];
-    for (int t = 1; t < threads; ++t) pool[t] = std::thread(work, t);
-    work(0);
-    for (int t = 1; t < threads; ++t) pool[t].join();
+    work(0, 1);
+    return TSDF_OK;
   }
+  // std::thread's constructor may throw (std::system_error: no resources); nothing may cross the C boundary, so the
+  // shares of workers that could not be started are copied here
+  std::thread pool[64];
+  int started = 1;  // share 0 is this thread's
+  try {
+    for (; started < threads; ++started) pool[started] = std::thread(work, started, threads);
+  } catch (...) {
+  }
+  work(0, threads);
+  for (int t = started; t < threads; ++t) work(t, threads);
+  for (int t = 1; t < started; ++t) pool[t].join();
   return TSDF_OK;
+}
+
+int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_t n_src, const int64_t *index, int64_t n,
+                            float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads) {
+  return host_gather(src, -1, src_offsets, n_src, index, n, dst, dst_capacity, dst_offsets, threads);
+}
+
+int tsdf_host_gather_frames_n(const float *src, int64_t src_len, const int64_t *src_offsets, int64_t n_src,
+                              const int64_t *index, int64_t n, float *dst, int64_t dst_capacity, int64_t *dst_offsets,
+                              int threads) {
+  if (src_len < 0) return TSDF_ERR_INVALID_ARG;
+  return host_gather(src, src_len, src_offsets, n_src, index, n, dst, dst_capacity, dst_offsets, threads);
 }
 
 const char *tsdf_strerror(int status) {

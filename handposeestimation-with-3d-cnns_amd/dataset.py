@@ -233,16 +233,45 @@ class VoxelBatch(NamedTuple):
 
 
 def plan_batches(n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle: bool = False, seed: int = 0,
-                 epoch: int = 0, drop_last: bool = False, weights: Optional[np.ndarray] = None) -> List[np.ndarray]:
+                 epoch: int = 0, drop_last: bool = False, weights: Optional[np.ndarray] = None,
+                 balance: Optional[str] = None) -> List[np.ndarray]:
     """The frame indices of every batch of one epoch for one rank.  Ranks own CONTIGUOUS shards of the frame range
-    (``shard.shard_bounds``, balanced by ``weights`` = pixels per frame when given) — the split BASELINE.json
-    configs[3] names; shuffling permutes inside the rank's shard.  No collective is involved."""
-    a, b = shard.shard_for_rank(n, rank, world, weights)
+    (``shard.shard_bounds``) — the split BASELINE.json configs[3] names; shuffling permutes inside the rank's shard.
+    No collective is involved.
+
+    balance  ``"frames"``: shards of equal frame count (sizes differ by at most one) and THE SAME NUMBER OF BATCHES ON
+             EVERY RANK — what a training loop that steps a gradient collective once per batch needs.  A rank that is
+             one frame short of another batch repeats its first frame in a final one-frame batch (as
+             ``torch.utils.data.DistributedSampler`` pads); with ``drop_last`` every rank keeps
+             ``min(shard) // batch_size`` full batches.
+             ``"pixels"``: cut points balance ``weights`` (pixels per frame; MSRA boxes vary ~3x in area): equal WORK per
+             rank, for voxelization / export jobs that never synchronise per batch.  Frame and batch counts then differ
+             between ranks (8 ranks over MSRA-like subjects: 7 to 15 batches of 1024).
+             Default: ``"pixels"`` when ``weights`` is given, else ``"frames"``.
+    """
+    if balance is None:
+        balance = "pixels" if weights is not None else "frames"
+    if balance not in ("frames", "pixels"):
+        raise ValueError("balance must be 'frames' or 'pixels'")
+    if balance == "pixels" and weights is None:
+        raise ValueError("balance='pixels' needs the per-frame weights")
+    bounds = shard.shard_bounds(n, world, weights if balance == "pixels" else None)
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    a, b = bounds[rank]
     idx = np.arange(a, b, dtype=np.int64)
     if shuffle:
         np.random.default_rng((seed, epoch, rank)).shuffle(idx)
     batches = [idx[i:i + batch_size] for i in range(0, idx.size, batch_size)]
-    if drop_last and batches and batches[-1].size < batch_size:
+    if balance == "frames":
+        lens = [e - s for s, e in bounds]
+        if drop_last:
+            batches = batches[: min(lens) // batch_size]
+        else:
+            want = -(-max(lens) // batch_size)
+            while len(batches) < want and idx.size:
+                batches.append(idx[:1].copy())       # pad: one repeated frame (only ever one batch: sizes differ by <= 1)
+    elif drop_last and batches and batches[-1].size < batch_size:
         batches.pop()
     return batches
 
@@ -283,7 +312,12 @@ class VoxelLoader:
     def __init__(self, dataset: MSRADepthDataset, batch_size: int, device, res: int = 32,
                  shuffle: bool = False, seed: int = 0, drop_last: bool = False,
                  rank: int = 0, world: int = 1, labels: bool = True, clamp: bool = True,
-                 max_pixels: Optional[int] = None, layout: str = "czyx", pin_packs: bool = True):
+                 max_pixels: Optional[int] = None, layout: str = "czyx", pin_packs: bool = True,
+                 balance: str = "frames"):
+        """``balance``: how ranks split the frames (:func:`plan_batches`): ``"frames"`` (default) gives every rank the same
+        number of batches — required when the consumer synchronises per batch (DDP); ``"pixels"`` equalises the
+        voxelization work instead (export jobs)."""
+        self.balance = balance
         self.ds, self.bs, self.device, self.res = dataset, int(batch_size), torch.device(device), res
         self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.rank, self.world = rank, world
@@ -296,7 +330,7 @@ class VoxelLoader:
 
     def _batches(self) -> List[np.ndarray]:
         return plan_batches(len(self.ds), self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch,
-                            self.drop_last, self.ds.pixels())
+                            self.drop_last, self.ds.pixels() if self.balance == "pixels" else None, self.balance)
 
     def __len__(self) -> int:
         return len(self._batches())
@@ -352,9 +386,11 @@ class VoxelLoader:
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         copy_stream = self._copy_stream
-        cur = torch.cuda.current_stream(self.device)
         try:
             for k in range(len(batches)):
+                # the stream the consumer is on NOW: a generator may be resumed under another torch.cuda.stream(...)
+                # context than the one it was started in, and the launch below goes to whatever is current
+                cur = torch.cuda.current_stream(self.device)
                 s = sets[k & 1]
                 s.filled.wait()
                 if not err.empty():
@@ -421,17 +457,33 @@ class ResidentLoader:
     ONCE and every batch is drawn by index on the device (``tsdf_voxelize_indexed_hip``): a training step sends n frame
     indices, nothing else.  Same arguments, same batches (:func:`plan_batches`) and same :class:`VoxelBatch` as
     ``VoxelLoader``; the dataset must be pack-backed (``MSRADepthDataset(packed_dir=...)`` / ``from_packs``).
+
+    ``prefetch=k`` (k > 1) takes the host out of the step for SMALL batches — the reference trains with batch 16
+    (3D_CNN/train.py:36), where one launch per batch is bound by Python, not by the GPU: the epoch's permutation is
+    uploaded once, ONE launch voxelizes k consecutive batches (k*batch_size frames: the fused kernel's regime) into a
+    ring buffer, and the loader yields k prebuilt ``batch_size``-frame views of it.  The batches are the same frames in
+    the same order with the same values as with ``prefetch=1``; what changes is their lifetime: a batch's tensors are
+    views of a ring of ``ring`` blocks and are overwritten once ``(ring - 1) * k`` further batches have been drawn (on the
+    stream that was current when the block was launched — a consumer on that stream can never observe the overwrite;
+    clone what you keep).  ``augment=True`` draws its maps per batch exactly as without prefetch.  The ``augment`` draws
+    use numpy's ``Generator`` seeded per (seed, epoch, rank, batch): the reference's distributions, not its legacy stream.
     """
 
     def __init__(self, dataset: MSRADepthDataset, batch_size: int, device, res: int = 32, shuffle: bool = False,
                  seed: int = 0, drop_last: bool = False, rank: int = 0, world: int = 1, labels: bool = True,
-                 clamp: bool = True, layout: str = "czyx", augment: bool = False):
+                 clamp: bool = True, layout: str = "czyx", augment: bool = False, balance: str = "frames",
+                 prefetch: int = 1, ring: int = 2):
         """``augment=True``: every frame of every batch gets a fresh 3-D augmentation with the reference's distributions
         (``augment.random_affines``, pre/process.py:209-216) about its own un-augmented grid centre, fused into the
-        voxelizer (BASELINE configs[4]); the yielded ``gt`` are then the mapped joints, ``gt_nor`` their labels."""
+        voxelizer (BASELINE configs[4]); the yielded ``gt`` are then the mapped joints, ``gt_nor`` their labels.
+        ``balance``: see :func:`plan_batches` (``"frames"``: every rank yields the same number of batches)."""
         if not dataset.packed:
             raise ValueError("ResidentLoader needs a pack-backed dataset (packing.pack_tree + packed_dir=, or from_packs)")
+        if prefetch < 1 or ring < 2:
+            raise ValueError("prefetch must be >= 1 and ring >= 2")
         self.augment = bool(augment)
+        self.balance = balance
+        self.prefetch, self.ring = int(prefetch), int(ring)
         self.ds, self.bs, self.device, self.res = dataset, int(batch_size), torch.device(device), res
         self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.rank, self.world = rank, world
@@ -440,6 +492,7 @@ class ResidentLoader:
         self._dev = None   # (depth, offsets, headers, gt) of all packs, on the device
         self._g = None     # dataset frame -> frame of the concatenated packs
         self._idx = None   # two pinned index buffers + the events of the launches that read them
+        self._blocks = None  # prefetch > 1: the ring of output blocks and their prebuilt batch views
 
     def resident_bytes(self) -> int:
         return sum(4 * int(pk.depth.size) for pk in self.ds.packs)
@@ -459,7 +512,7 @@ class ResidentLoader:
 
     def _batches(self) -> List[np.ndarray]:
         return plan_batches(len(self.ds), self.bs, self.rank, self.world, self.shuffle, self.seed, self.epoch,
-                            self.drop_last, self.ds.pixels())
+                            self.drop_last, self.ds.pixels() if self.balance == "pixels" else None, self.balance)
 
     def __len__(self) -> int:
         return len(self._batches())
@@ -469,9 +522,14 @@ class ResidentLoader:
         self.epoch += 1
         if self._dev is None:
             self._upload()
+        if self.prefetch > 1:
+            return self._iter_blocks(batches, self.epoch)
+        return self._iter_single(batches, self.epoch)
+
+    def _iter_single(self, batches, epoch) -> Iterator[VoxelBatch]:
         depth, off, hdr, gt = self._dev
-        cur = torch.cuda.current_stream(self.device)
         for k, b in enumerate(batches):
+            cur = torch.cuda.current_stream(self.device)   # (per batch: the consumer may have switched streams)
             h_idx, done = self._idx[k & 1]
             if self._used[k & 1]:
                 done.synchronize()          # the launch that read this index buffer two batches ago
@@ -482,13 +540,100 @@ class ResidentLoader:
             if self.augment:
                 from . import augment as _aug
                 h_xf = self._xf[k & 1]
-                h_xf.numpy()[:n] = _aug.random_affines(self._mid[gidx], rng=(self.seed, self.epoch, self.rank, k))[0]
+                h_xf.numpy()[:n] = _aug.random_affines(self._mid[gidx], rng=(self.seed, epoch, self.rank, k))[0]
                 xf = h_xf[:n].to(self.device, non_blocking=True)   # (read per voxel: device memory, not the link)
             out, gt_nor, g = voxelize_indexed(depth, off, hdr, h_idx[:n], gt, res=self.res, layout=self.layout,
                                               clamp=self.clamp, gt_copy=True, xforms=xf)
             done.record(cur)
             self._used[k & 1] = True
             yield VoxelBatch(out.tsdf, g, out.max_l, out.mid_p, out.status, gt_nor if self.labels else None)
+
+    # ---- prefetch > 1: one launch per block of `prefetch` batches ----
+    def _make_blocks(self):
+        depth, off, hdr, gt = self._dev
+        cap, R = self.bs * self.prefetch, self.res
+        lab_shape = (cap,) + tuple(gt.shape[1:])
+        blocks = []
+        for _ in range(self.ring):
+            out = TsdfBatch(torch.empty((cap, 3, R, R, R), dtype=torch.float32, device=self.device),
+                            torch.empty((cap,), dtype=torch.float32, device=self.device),
+                            torch.empty((cap, 3), dtype=torch.float32, device=self.device),
+                            torch.empty((cap,), dtype=torch.int32, device=self.device))
+            gt_nor = torch.empty(lab_shape, dtype=torch.float32, device=self.device)
+            g = torch.empty(lab_shape, dtype=torch.float32, device=self.device)
+            views = [self._view(out, gt_nor, g, j * self.bs, (j + 1) * self.bs) for j in range(self.prefetch)]
+            blocks.append((out, gt_nor, g, views))
+        return blocks
+
+    def _view(self, out, gt_nor, g, a, b) -> VoxelBatch:
+        return VoxelBatch(out.tsdf[a:b], g[a:b], out.max_l[a:b], out.mid_p[a:b], out.status[a:b],
+                          gt_nor[a:b] if self.labels else None)
+
+    def _iter_blocks(self, batches, epoch) -> Iterator[VoxelBatch]:
+        depth, off, hdr, gt = self._dev
+        if self._blocks is None:
+            self._blocks = self._make_blocks()
+        if not batches:
+            return
+        bs, P = self.bs, self.prefetch
+        # the epoch's permutation goes up once; a launch reads its slice of it
+        flat = np.concatenate(batches)
+        gidx = self._g[flat]
+        d_idx = torch.from_numpy(np.ascontiguousarray(gidx)).to(self.device)
+        d_xf = None
+        if self.augment:   # the same draws as without prefetch: one generator per batch
+            from . import augment as _aug
+            xf = np.empty((flat.size, 24), np.float64)
+            pos = 0
+            for k, b in enumerate(batches):
+                xf[pos:pos + b.size] = _aug.random_affines(self._mid[gidx[pos:pos + b.size]],
+                                                           rng=(self.seed, epoch, self.rank, k))[0]
+                pos += b.size
+            d_xf = torch.from_numpy(xf).to(self.device)
+        pos = 0
+        for blk, k0 in enumerate(range(0, len(batches), P)):
+            mine = batches[k0:k0 + P]
+            nfr = int(sum(b.size for b in mine))
+            out, gt_nor, g, views = self._blocks[blk % self.ring]
+            full = nfr == bs * P
+            if full:
+                o, gn, gg = out, gt_nor, g
+            else:      # the epoch's last block: the leading part of the ring entry
+                o = TsdfBatch(out.tsdf[:nfr], out.max_l[:nfr], out.mid_p[:nfr], out.status[:nfr])
+                gn, gg = gt_nor[:nfr], g[:nfr]
+            voxelize_indexed(depth, off, hdr, d_idx[pos:pos + nfr], gt, res=self.res, layout=self.layout, clamp=self.clamp,
+                             out=o, out_gt_nor=gn, out_gt=gg,
+                             xforms=None if d_xf is None else d_xf[pos:pos + nfr])
+            pos += nfr
+            if full:
+                yield from views
+            else:
+                a = 0
+                for b in mine:
+                    yield self._view(out, gt_nor, g, a, a + int(b.size))
+                    a += int(b.size)
+
+
+class PreBatched:
+    """What :meth:`MSRA_Dataset.__getitems__` hands to torch's DataLoader: the batch, ALREADY batched.  torch's
+    ``default_collate`` dispatches on the type of ``batch[0]``; this type is registered with it (below), so the list
+    ``[PreBatched(batch)]`` collates to ``batch`` itself — no per-item views, no ``torch.stack``."""
+
+    __slots__ = ("batch",)
+
+    def __init__(self, batch):
+        self.batch = batch
+
+
+def _collate_prebatched(batch, *, collate_fn_map=None):
+    return batch[0].batch
+
+
+try:   # the documented extension point of torch.utils.data.default_collate
+    from torch.utils.data._utils.collate import default_collate_fn_map as _collate_map
+    _collate_map[PreBatched] = _collate_prebatched
+except ImportError:   # pragma: no cover  (a torch without the map: MSRA_Dataset(prebatched=False) still works)
+    _collate_map = None
 
 
 class MSRA_Dataset(data.Dataset):
@@ -503,15 +648,24 @@ class MSRA_Dataset(data.Dataset):
     ``opt.size`` / ``opt.test_index`` are honoured when present (the reference ignores ``opt`` and hard-codes
     ``'small'`` / 2, :20-22); ``aug=True`` is rejected like ``DataProcess(aug=True)``: use ``voxelize_aug``.
 
-    Under the reference's own ``DataLoader(dataset, batch_size=B, shuffle=True)`` (train.py:137-141; ``num_workers=0``:
+    Under the reference's own ``DataLoader(dataset, batch_size=B, shuffle=True)`` (train.py:36,86-91; ``num_workers=0``:
     the items are GPU tensors) the loader hands the batch's indices to :meth:`__getitems__`, which voxelizes exactly
-    those B frames in ONE launch; a lone ``dataset[i]`` voxelizes frame i alone unless the access pattern is a sequential
-    walk, which is served from a block.  For training throughput use :class:`VoxelLoader`, which overlaps reading,
-    upload and voxelization.
+    those B frames in ONE launch and returns them ALREADY BATCHED (``prebatched=True``, the default on a resident
+    dataset): the indices go into a page-locked ring the kernel reads over the link, the outputs into a ring of
+    preallocated batches, and the result is a :class:`PreBatched` that torch's ``default_collate`` unwraps — the host
+    side of a step is one index conversion and one C call.  What the ``DataLoader`` yields is the reference's collated
+    batch ``(tsdf[B,3,32,32,32], gt[B,63], max_l[B], mid_p[B,3])``, on the GPU.  The ring recycles a batch's tensors after
+    ``ring`` further batches (default: as many as fit 2 GiB, at most 256; stream-ordered, so a consumer on the launch
+    stream never sees it — clone what you keep longer).  With a custom ``collate_fn`` pass ``prebatched=False``: a list of
+    item tuples, views into the batch's tensors, as torch documents for ``__getitems__``.
+    A lone ``dataset[i]`` voxelizes frame i alone unless the access pattern is a sequential walk, which is served
+    from a block.  For the highest throughput at small batch sizes use :class:`ResidentLoader` with ``prefetch``: it
+    knows the epoch's permutation in advance, which nothing behind ``DataLoader`` can.
     """
 
     def __init__(self, root_path, opt=None, train=True, aug=False, device="cuda", block: int = 1024,
-                 packed_dir: Optional[str] = None, resident: Optional[bool] = None):
+                 packed_dir: Optional[str] = None, resident: Optional[bool] = None, prebatched: Optional[bool] = None,
+                 ring: Optional[int] = None, _raw: Optional[MSRADepthDataset] = None):
         if aug:
             raise NotImplementedError("aug=True: the reference loads '_aug' files its preprocessing cannot produce "
                                       "(data_aug raises AxisError); use voxelize_aug for on-the-fly augmentation")
@@ -519,8 +673,8 @@ class MSRA_Dataset(data.Dataset):
         self.test_idx = int(getattr(opt, "test_index", 2))
         self.PCA_SZ = int(getattr(opt, "PCA_SZ", 63))
         self.train = train
-        self.raw = MSRADepthDataset(root_path, train=train, test_idx=self.test_idx, size=self.size,
-                                    packed_dir=packed_dir)
+        self.raw = _raw if _raw is not None else MSRADepthDataset(root_path, train=train, test_idx=self.test_idx,
+                                                                  size=self.size, packed_dir=packed_dir)
         self.device = torch.device(device)
         self.block = int(block)
         self._cache_block = -1
@@ -530,7 +684,17 @@ class MSRA_Dataset(data.Dataset):
         # resident (default: whenever the dataset is pack-backed): the packs go to the GPU once and a batch is a list of
         # indices resolved on the device (tsdf_voxelize_indexed_hip) — no crop crosses the link after start-up
         self.resident = self.raw.packed if resident is None else bool(resident)
+        self.prebatched = (self.resident and _collate_map is not None) if prebatched is None else bool(prebatched)
+        if self.prebatched and not self.resident:
+            raise ValueError("prebatched=True needs a resident (pack-backed) dataset")
+        self._ring_req = ring
         self._rp: Optional[ResidentPacks] = None
+        self._fast = None        # the ring of the pre-batched path (built on the first batch)
+
+    @classmethod
+    def from_raw(cls, raw: MSRADepthDataset, device="cuda", **kw) -> "MSRA_Dataset":
+        """The on-the-fly dataset over raw frames that are already open (``MSRADepthDataset`` / ``from_packs``)."""
+        return cls(None, device=device, _raw=raw, **kw)
 
     def __len__(self):
         return len(self.raw)
@@ -550,19 +714,95 @@ class MSRA_Dataset(data.Dataset):
             self._cache_gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
         self._cache_block = blk
 
+    # ---- the pre-batched path: one C call per batch, nothing allocated, nothing sliced ----
+    class _Fast:
+        """Ring state for batches of (at most) ``bs`` frames: page-locked index slots the kernel reads over the link,
+        output slots, one prebuilt result per slot, the C call's constant arguments, and one event per ``kGroup`` slots
+        that tells when their index words have been read (a slot's words are rewritten ``ring`` batches later)."""
+
+        kGroup = 16
+
+        def __init__(self, rp: "ResidentPacks", bs: int, ring: int, device):
+            import ctypes
+            from . import _lib
+            ring = -(-ring // self.kGroup) * self.kGroup
+            self.bs, self.ring, self.slot = bs, ring, 0
+            self.L = _lib.load()
+            R = 32
+            self.h_idx = torch.empty((ring, bs), dtype=torch.int64).pin_memory()
+            self.h_idx_np = self.h_idx.numpy()
+            self.tsdf = torch.empty((ring, bs, 3, R, R, R), dtype=torch.float32, device=device)
+            self.max_l = torch.empty((ring, bs), dtype=torch.float32, device=device)
+            self.mid_p = torch.empty((ring, bs, 3), dtype=torch.float32, device=device)
+            self.status = torch.empty((ring, bs), dtype=torch.int32, device=device)
+            nc = rp.gt.shape[1]
+            self.gt = torch.empty((ring, bs, nc), dtype=torch.float32, device=device)
+            self.gt_nor = torch.empty((ring, bs, nc), dtype=torch.float32, device=device)
+            self.labels = [_lib.TsdfLabels(rp.gt.data_ptr(), nc // 3, 1, self.gt_nor[k].data_ptr(), self.gt[k].data_ptr())
+                           for k in range(ring)]
+            self.head = (rp.depth.data_ptr(), rp.depth.numel(), rp.offsets.data_ptr(), rp.headers.data_ptr(),
+                         int(rp.headers.shape[0]))
+            self.args = [(self.h_idx[k].data_ptr(), self.tsdf[k].data_ptr(), self.max_l[k].data_ptr(),
+                          self.mid_p[k].data_ptr(), self.status[k].data_ptr(), ctypes.byref(self.labels[k]))
+                         for k in range(ring)]
+            self.results = [[PreBatched((self.tsdf[k], self.gt[k], self.max_l[k], self.mid_p[k]))] for k in range(ring)]
+            self.read = [torch.cuda.Event() for _ in range(ring // self.kGroup)]
+            self.read_used = [False] * (ring // self.kGroup)
+            d = torch.device(device)
+            self.device = d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def _fast_batch(self, indices):
+        from .voxelize import _raw_stream, _Current
+        from . import _lib
+        rp = self._rp
+        n = len(indices)
+        f = self._fast
+        if f is None or n > f.bs:
+            vol = n * (3 * 32 ** 3 * 4)
+            ring = self._ring_req if self._ring_req else max(16, min(256, (2 << 30) // max(vol, 1)))
+            f = self._fast = MSRA_Dataset._Fast(rp, n, ring, self.device)
+        k = f.slot
+        g, within = divmod(k, f.kGroup)
+        if within == 0 and f.read_used[g]:
+            f.read[g].synchronize()      # the launches that read this group's index words a ring ago are done
+        f.h_idx_np[k, :n] = rp.frame[indices]
+        a = f.args[k]
+        with _Current(f.device):
+            rc = f.L.tsdf_voxelize_indexed_hip(*f.head, a[0], n, 32, None, 0, _raw_stream(f.device), a[1], a[2], a[3],
+                                               a[4], a[5])
+            if within == f.kGroup - 1:
+                f.read[g].record(torch.cuda.current_stream(f.device))
+                f.read_used[g] = True
+        if rc != 0:
+            _lib.check(rc, "tsdf_voxelize_indexed_hip")
+        f.slot = k + 1 if k + 1 < f.ring else 0
+        if n == f.bs:
+            return f.results[k]
+        return [PreBatched((f.tsdf[k, :n], f.gt[k, :n], f.max_l[k, :n], f.mid_p[k, :n]))]   # the epoch's short last batch
+
     def __getitems__(self, indices):
         """The frames of one batch, voxelized by one launch (torch's DataLoader calls this with the batch's indices
-        when it exists): a list of item tuples, views into the batch's tensors."""
+        when it exists).  ``prebatched``: ``[PreBatched(batch)]``, which ``default_collate`` turns into the batch; else a
+        list of item tuples, views into the batch's tensors."""
         if data.get_worker_info() is not None:
             raise RuntimeError("MSRA_Dataset produces its items on the GPU: use it with num_workers=0 (the reference's "
                                "default, train.py:38), there is nothing for loader processes to do")
+        if self.resident and self._rp is None:
+            self._rp = ResidentPacks(self.raw, self.device)
+        if self.prebatched:
+            n_all = len(self.raw)
+            if not indices:
+                raise IndexError("empty batch")
+            lo, hi = min(indices), max(indices)
+            if lo < 0 or hi >= n_all:
+                raise IndexError(int(hi if hi >= n_all else lo))
+            self._last = int(indices[-1])
+            return self._fast_batch(indices)
         idx = np.asarray([int(i) for i in indices], np.int64)
         if idx.size and (idx.min() < 0 or idx.max() >= len(self.raw)):
             raise IndexError(int(idx.max() if idx.max() >= len(self.raw) else idx.min()))
         self._last = int(idx[-1]) if idx.size else self._last
         if self.resident:
-            if self._rp is None:
-                self._rp = ResidentPacks(self.raw, self.device)
             rp = self._rp
             out, _, gt = voxelize_indexed(rp.depth, rp.offsets, rp.headers,
                                           torch.from_numpy(rp.frame[idx]).to(self.device), rp.gt, gt_copy=True)
@@ -573,6 +813,14 @@ class MSRA_Dataset(data.Dataset):
         gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
         return [(out.tsdf[k], gt[k], out.max_l[k], out.mid_p[k]) for k in range(idx.size)]
 
+    def _items_of(self, indices):
+        """``indices`` as a list of item tuples whatever ``prebatched`` says (single-item access)."""
+        r = self.__getitems__(indices)
+        if r and isinstance(r[0], PreBatched):
+            b = r[0].batch
+            return [tuple(t[k].clone() for t in b) for k in range(len(indices))]   # (out of the ring: the item outlives it)
+        return r
+
     def __getitem__(self, index):
         index = int(index)
         if not 0 <= index < len(self.raw):
@@ -580,7 +828,7 @@ class MSRA_Dataset(data.Dataset):
         blk = index // self.block
         if blk != self._cache_block:
             if index != self._last + 1 and index % self.block:   # random access: this frame alone
-                return self.__getitems__([index])[0]
+                return self._items_of([index])[0]
             self._load_block(blk)                                 # a sequential walk: the whole block at once
         self._last = index
         k = index - blk * self.block

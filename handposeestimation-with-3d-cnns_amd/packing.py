@@ -52,9 +52,11 @@ def _native_gather(pk, idx: np.ndarray, out: np.ndarray, off: np.ndarray) -> boo
         return False
     idx = np.ascontiguousarray(idx, np.int64)
     off2 = np.empty_like(off)
-    rc = L.tsdf_host_gather_frames(src.ctypes.data, so.ctypes.data, so.size - 1, idx.ctypes.data, idx.size, out.ctypes.data,
-                                   out.size, off2.ctypes.data, _GATHER_THREADS)
-    return rc == 0 and bool((off2 == off).all())
+    rc = L.tsdf_host_gather_frames_n(src.ctypes.data, src.size, so.ctypes.data, so.size - 1, idx.ctypes.data, idx.size,
+                                     out.ctypes.data, out.size, off2.ctypes.data, _GATHER_THREADS)
+    if rc != 0:
+        raise ValueError("pack offsets do not describe its depth payload (damaged pack?)")
+    return bool((off2 == off).all())
 
 
 def _pad(n: int) -> int:
@@ -222,6 +224,14 @@ class PackedFrames:
         depth, _ = arr(pos, np.float32, (n_px,))
         if n and (int(offsets[0]) != 0 or int(offsets[-1]) != n_px):
             raise ValueError(f"{path}: offsets do not match the depth payload")
+        if n:   # every interior offset too, and every header against its payload (vectorised; reads n*32 bytes)
+            o = np.asarray(offsets)
+            if (np.diff(o) < 0).any():
+                raise ValueError(f"{path}: offsets are not non-decreasing (damaged pack)")
+            h = np.asarray(headers).astype(np.int64)
+            if ((h[:, 4] - h[:, 2]) * (h[:, 5] - h[:, 3]) != np.diff(o)).any() or (h[:, 4] <= h[:, 2]).any() \
+                    or (h[:, 5] <= h[:, 3]).any():
+                raise ValueError(f"{path}: a header contradicts its payload (damaged pack)")
         return PackedFrames(depth, offsets, headers, gt, np.asarray(gs), names)
 
     def frame(self, i: int) -> Tuple[np.ndarray, np.ndarray]:

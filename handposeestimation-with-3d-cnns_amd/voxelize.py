@@ -191,14 +191,17 @@ def voxelize_labels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.T
 def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, index: torch.Tensor,
                      gt: Optional[torch.Tensor] = None, res: int = 32, layout: str = "czyx",
                      cam: Optional[_lib.TsdfCam] = None, clamp: bool = True, out: Optional[TsdfBatch] = None,
-                     gt_copy: bool = False, xforms: Optional[torch.Tensor] = None):
+                     gt_copy: bool = False, xforms: Optional[torch.Tensor] = None,
+                     out_gt_nor: Optional[torch.Tensor] = None, out_gt: Optional[torch.Tensor] = None):
     """A batch drawn by index from a pack that lives on the GPU (``tsdf_voxelize_indexed_hip``): ``depth`` /
     ``offsets[N+1]`` / ``headers[N,6]`` (and ``gt[N,3J]``) describe the whole pack, uploaded once; frame i of the batch is
     pack frame ``index[i]`` (int64[n], any order — a shuffled minibatch; device or pinned host memory).  Outputs are in
     batch order.  Bit-identical to :func:`voxelize_labels` on the gathered frames.  Returns ``TsdfBatch`` without ``gt``,
     else ``(TsdfBatch, gt_nor)`` or, with ``gt_copy=True``, ``(TsdfBatch, gt_nor, gt_of_the_batch)``.
     ``xforms`` float64[n,24] on the GPU (one map per batch position, as for :func:`voxelize_aug`) adds the fused 3-D
-    augmentation: the labels are then mapped with it, ``gt_of_the_batch`` is ``T(joints)``."""
+    augmentation: the labels are then mapped with it, ``gt_of_the_batch`` is ``T(joints)``.
+    ``out`` / ``out_gt_nor`` / ``out_gt`` (the latter implies ``gt_copy``): preallocated outputs of exactly the batch's
+    shapes — a loader's ring buffers; nothing is allocated then."""
     L = _lib.load()
     _dev_check("index", index, torch.int64, depth.device if isinstance(depth, torch.Tensor) else None, host_ok=True)
     if index.dim() != 1:
@@ -218,8 +221,15 @@ def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.
         nc = gt.numel() // n_pack if n_pack else 63
         if nc % 3 or not 1 <= nc // 3 <= 170:
             raise ValueError("gt must hold 1..170 joints of 3 coordinates per frame")
-        gt_nor = torch.empty((n,) + tuple(gt.shape[1:]), dtype=torch.float32, device=dev)
-        gt_dev = torch.empty_like(gt_nor) if gt_copy else None
+        shape = (n,) + tuple(gt.shape[1:])
+        for name, t in (("out_gt_nor", out_gt_nor), ("out_gt", out_gt)):
+            if t is not None:
+                _dev_check(name, t, torch.float32, dev)
+                if tuple(t.shape) != shape:
+                    raise ValueError(f"{name} must have shape {shape}")
+        gt_nor = out_gt_nor if out_gt_nor is not None else torch.empty(shape, dtype=torch.float32, device=dev)
+        gt_copy = gt_copy or out_gt is not None
+        gt_dev = out_gt if out_gt is not None else (torch.empty_like(gt_nor) if gt_copy else None)
         lab = _lib.TsdfLabels(gt.data_ptr(), nc // 3, 1 if clamp else 0, gt_nor.data_ptr(),
                               gt_dev.data_ptr() if gt_dev is not None else None)
     if n:
@@ -285,9 +295,12 @@ def _norm_call(x, max_l, mid_p, clamp, inverse, out):
 
 
 def release_stream(stream=None) -> None:
-    """Tell the library that ``stream`` (default: the current one) is going away (``tsdf_stream_release``)."""
+    """Tell the library that ``stream`` (default: the current one) is going away (``tsdf_stream_release``).  The
+    stream is synchronised first: its work-queue word and mailboxes must not be handed to another stream while one of
+    its launches is still running (include/tsdf.h, "stream ownership")."""
     L = _lib.load()
     s = stream if stream is not None else torch.cuda.current_stream()
+    s.synchronize()
     L.tsdf_stream_release(s.cuda_stream)
 
 

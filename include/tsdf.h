@@ -24,7 +24,13 @@
  *     workgroups dynamically): an eager launch uses a device-side queue word owned by
  *     its (device, stream) pair — launches on one stream execute in order, so the word
  *     is never shared, however many launches are in flight; the library keeps one word
- *     per stream it has seen (tsdf_stream_release returns it).  A launch issued while
+ *     per stream it has seen (tsdf_stream_release returns it).  STREAM OWNERSHIP: the word (and the
+ *     mailboxes of small batches) are keyed by the hipStream_t value, so a stream must not be destroyed — and
+ *     tsdf_stream_release must not be called for it — while one of its voxelizer launches is still in flight:
+ *     hipStreamDestroy returns at once and lets the work drain, and a new stream that is handed the same
+ *     value would share the word with the launch still draining (two launches drawing tickets from one word
+ *     skip frames silently).  Synchronise the stream first; destroying or releasing a busy stream is
+ *     undefined.  A launch issued while
  *     its stream is being captured, on hipStreamPerThread from more threads than there
  *     are words, or on a stream beyond the 1024th distinct one uses no global state at
  *     all: its workgroups then share frames through a counter in their own LDS (static
@@ -46,7 +52,7 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 4
+#define TSDF_ABI_VERSION 5
 
 /* Output volume layouts.  Both hold float32[n][3][R][R][R]; channel c = x,y,z component. */
 enum tsdf_layout {
@@ -174,12 +180,22 @@ int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_
  *
  *   d_xforms  float64[n][24]  per frame: the forward affine map T(p) = A p + b as three rows
  *                             {A_i0, A_i1, A_i2, b_i}, then its inverse in the same form.
- *   The AABB / grid placement is that of the mapped cloud T(p) over all valid pixels; a voxel centre v'
- *   of that grid is mapped back (T^-1), projected and gathered as in tsdf_voxelize_hip, the surface
- *   point is mapped forward and the truncated distances are taken between v' and T(w).
- *   T is evaluated as fma(A_i0, x, fma(A_i1, y, fma(A_i2, z, b_i))) per row, T^-1 with separately rounded
- *   products and sums grouped as (A_i0 x + A_i1 y) + (A_i2 z + b_i) (float64 both).
- *   With the identity map the result equals tsdf_voxelize_hip.  max_l / mid_p are in the mapped frame.
+ *   The AABB / grid placement is that of the mapped cloud T(p) over all valid pixels (T evaluated as
+ *   fma(A_i0, x, fma(A_i1, y, fma(A_i2, z, b_i))) per row, then rounded to float32); a voxel centre v' of that
+ *   grid is mapped back (T^-1 with separately rounded products and sums grouped as (A_i0 x + A_i1 y) +
+ *   (A_i2 z + b_i)), projected and gathered as in tsdf_voxelize_hip, and the truncated distances are those
+ *   between v' and T(w), w the surface point of the gathered pixel.  ABI v5 states them in the cheapest exact
+ *   form an affine T allows (the kernel is VALU-bound; v4 formed w and T(w) explicitly, about twice the float64
+ *   work per voxel): with dxi = pix_x - cx, dyi = pix_y - cy, iF = 1/F, it = 1/trunc_dis, float64, one rounding
+ *   per operation,
+ *       g_i0 = -(A_i0 * iF),  g_i1 = A_i1 * iF                          per frame
+ *       c_i  = fma(g_i0, dxi, fma(g_i1, dyi, A_i2))
+ *       u_i  = fma(pd, c_i, v'_i - b_i)                                 = v'_i - T(w)_i in mm
+ *       t_i  = u_i * it ;  near iff fma(t_z, t_z, fma(t_y, t_y, t_x * t_x)) <= 1
+ *       value_i = near ? min(|t_i|, 1) : 1, negated iff u_z < 0         (pre/tsdf_numba.py:47-68)
+ *   With the identity map the grid, the pixel every voxel gathers, the zero mask, the sign and the z component
+ *   equal tsdf_voxelize_hip bit for bit and x / y agree to the float32 rounding (<= 1e-5 by a wide margin).
+ *   max_l / mid_p are in the mapped frame.
  */
 int tsdf_voxelize_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
                           int n, int R, const tsdf_cam *cam, int layout, void *hip_stream,
@@ -266,6 +282,18 @@ int tsdf_voxelize_indexed_aug_hip(const float *d_depth, int64_t depth_len, const
 int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_t n_src, const int64_t *index, int64_t n,
                             float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads);
 
+/* ---- ABI v5 additions ---------------------------------------------------------------------------- */
+
+/* tsdf_host_gather_frames with the LENGTH of the source buffer (src_len elements): a frame whose
+ * [src_offsets[f], src_offsets[f+1]) does not lie inside [0, src_len) — a damaged pack file — makes the call return
+ * TSDF_ERR_INVALID_ARG before anything is copied, instead of reading outside the mapping.  The v4 entry above trusts
+ * src_offsets (kept for v4 callers; it now applies the same checks with src_len = "unknown": negative offsets and
+ * decreasing pairs are still refused).  Neither ever throws: if worker threads cannot be started the copy runs on the
+ * calling thread. */
+int tsdf_host_gather_frames_n(const float *src, int64_t src_len, const int64_t *src_offsets, int64_t n_src,
+                              const int64_t *index, int64_t n, float *dst, int64_t dst_capacity, int64_t *dst_offsets,
+                              int threads);
+
 /* The normalisation on its own, from max_l / mid_p already on the device (pre/joint_nor.py:8-18), and its
  * inverse for predictions, (pred - 0.5) * max_l + mid_p (3D_CNN/train.py:263-266).  Frames with max_l == 0:
  * 0.5 / mid_p respectively. */
@@ -276,7 +304,7 @@ int tsdf_denormalize_joints_hip(const float *d_pred, const float *d_max_l, const
 
 /*
  * Diagnostic: the voxelizer with its pixel map.  Same kernel code path as tsdf_voxelize_hip /
- * tsdf_voxelize_grid_hip (d_grid NULL / non-NULL) — projection tables, row-span capture, gather — with one
+ * tsdf_voxelize_grid_hip (d_grid NULL / non-NULL) — projection tables, LDS-DMA staging, gather — with one
  * extra store per voxel:  d_out_pixmap int32[n][R][R][R], indexed [z][y][x] whatever the layout, holds the
  * gathered element index (pix_y - top) * b_w + pix_x - left (pre/tsdf_numba.py:38), -1 when the voxel
  * projects outside the bounding box (:36-37), -2 - index when the pixel there is invalid (:40-41).

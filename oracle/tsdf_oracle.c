@@ -264,16 +264,34 @@ int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32
  * (pre/process.py:202-261) raises AxisError on its own input and, where it runs (cut_version), only
  * moves the grid while the TSDF still samples the un-augmented depth image (App. B#8-9), so there is
  * NO reference output to match: this is a re-specification, parity unpinned, checked by construction
- * (identity transform == plain path, bit for bit) and against the HIP kernel.
+ * (identity transform == plain path: grid, pixel map, zero mask, sign and z component bit for bit, x / y to the
+ * float32 rounding) and against the HIP kernel.
  *
  * xf = double[24] per frame: forward affine T(p) = A p + b as rows {A_i0, A_i1, A_i2, b_i} (12 values),
  * then its inverse in the same form (12 values).  Every product/sum below is a separately rounded
  * float64 operation, in the order written (see affine3 / affine3_fwd).
  *   cloud:  p' = T(p) for the back-projected point p of every valid pixel (A.1, before the float32
  *           rounding), then rounded to float32 for the AABB -> glue as in the plain path;
- *   voxel:  centre v' lives in the augmented frame; v = T^-1(v') is projected (pre/tsdf_numba.py:30-32),
- *           the surface point w of that pixel (:43-46) is mapped forward, w' = T(w), and the
- *           truncated distances (:47-68) are taken between v' and w'.
+ *   voxel:  centre v' lives in the augmented frame; v = T^-1(v') is projected (pre/tsdf_numba.py:30-32) and the
+ *           pixel gathered and tested (:36-41) exactly as in the plain path.  The distances (:43-49) are those
+ *           between v' and w' = T(w), w the surface point of that pixel, written out for an affine T so that
+ *           the surface point itself never has to be formed: with dxi = pix_x - cx, dyi = pix_y - cy (:44-45),
+ *           w = pd * (dxi/F, -dyi/F, -1) and therefore, per axis i,
+ *               v'_i - w'_i = (v'_i - b_i) + pd * c_i,    c_i = -A_i0 dxi / F + A_i1 dyi / F + A_i2.
+ *           Evaluated (float64, one rounding per operation, fma where written) as
+ *               iF = 1 / F,  it = 1 / trunc_dis                                         (per frame)
+ *               g_i0 = -(A_i0 * iF),  g_i1 = A_i1 * iF                                  (per frame)
+ *               c_i = fma(g_i0, dxi, fma(g_i1, dyi, A_i2))
+ *               u_i = fma(pd, c_i, v'_i - b_i)                                          (mm)
+ *               t_i = u_i * it                                                          (:47-49, |.| taken below)
+ *               near  iff  fma(t_z, t_z, fma(t_y, t_y, t_x * t_x)) <= 1                 (:51-57, without the sqrt)
+ *               value_i = near ? min(|t_i|, 1) : 1 ;  negated iff u_z < 0               (:58-68: w'_z > v'_z)
+ *           With the identity map c = (-dxi * iF, dyi * iF, 1): u_z = pd + v_z exactly as rounded once, so the
+ *           sign and the z component are those of the plain path bit for bit; x and y differ from it in the
+ *           association of one product (<= 2 ulp of float64, i.e. nothing after the float32 store except at
+ *           the exact tie of a rounding).  Round 2 formed w and T(w) explicitly (about twice the float64
+ *           operations per voxel); the kernel that implements this contract is VALU-bound, which is why the
+ *           contract — a re-specification this project owns — is written in its cheapest exact form.
  */
 /* Inverse map (voxel centre back into the camera frame): every product and sum rounded separately, grouped as
  * (A_i0 x + A_i1 y) + (A_i2 z + b_i) — both brackets depend on grid indices only, so an implementation may
@@ -331,6 +349,14 @@ void tsdf_oracle_voxels_aug(const float *depth, const int32_t *header, const flo
   memset(out, 0, 3 * R3 * sizeof(float));
   const double F = cam->focal;
   const double *fwd = xf, *inv = xf + 12;
+  /* per-frame constants of the distance terms (see the contract above) */
+  const double iF = 1.0 / F, it = 1.0 / (double)trunc_dis;
+  double g0[3], g1[3];
+  for (int a = 0; a < 3; ++a) {
+    volatile double p0 = fwd[4 * a] * iF, p1 = fwd[4 * a + 1] * iF;
+    g0[a] = -p0;
+    g1[a] = p1;
+  }
   for (int z = 0; z < R; ++z)
     for (int y = 0; y < R; ++y)
       for (int x = 0; x < R; ++x) {
@@ -345,16 +371,24 @@ void tsdf_oracle_voxels_aug(const float *depth, const int32_t *header, const flo
         if (pix_x < l || pix_x >= r || pix_y < t || pix_y >= b) continue;
         const float pd = depth[(pix_y - t) * bw + pix_x - l];
         if (!(fabsf(pd) >= cam->invalid_eps)) continue;
-        const double q2 = (double)pd / F;
-        const double w[3] = {((double)pix_x - cam->cx) * q2, -((double)pix_y - cam->cy) * q2, -(double)pd};
-        double wp[3], ts[3];
-        affine3_fwd(fwd, w, wp);
-        for (int a = 0; a < 3; ++a) ts[a] = fabs(vp[a] - wp[a]) / (double)trunc_dis;
-        const double dist = sqrt(ts[0] * ts[0] + ts[1] * ts[1] + ts[2] * ts[2]);
-        if (dist > 1.0) ts[0] = ts[1] = ts[2] = 1.0;
-        for (int a = 0; a < 3; ++a)
-          if (1.0 < ts[a]) ts[a] = 1.0;
-        if (wp[2] > vp[2])
+        const double dxi = (double)pix_x - cam->cx, dyi = (double)pix_y - cam->cy;
+        double u[3], ts[3];
+        for (int a = 0; a < 3; ++a) {
+          const double c = fma(g0[a], dxi, fma(g1[a], dyi, fwd[4 * a + 2]));
+          volatile double vb = vp[a] - fwd[4 * a + 3];
+          u[a] = fma((double)pd, c, vb);                                  /* v'_a - w'_a, mm */
+          volatile double ta = u[a] * it;
+          ts[a] = ta;
+        }
+        volatile double xx = ts[0] * ts[0];
+        const double s2 = fma(ts[2], ts[2], fma(ts[1], ts[1], xx));
+        const int nearv = s2 <= 1.0;
+        for (int a = 0; a < 3; ++a) {
+          double m = fabs(ts[a]);
+          if (!(m < 1.0)) m = 1.0;             /* min(|t|, 1); a NaN distance counts as far */
+          ts[a] = nearv ? m : 1.0;
+        }
+        if (u[2] < 0.0)
           for (int a = 0; a < 3; ++a) ts[a] = -ts[a];
         const size_t vi = ((size_t)z * R + y) * R + x;
         for (int a = 0; a < 3; ++a) {

@@ -284,6 +284,24 @@ def test_packed_subject_blob_round_trip_and_fast_reader(pkg, synth, tmp_path):
     open(bad, "wb").write(b"NOTAPACK" + raw[8:])
     with pytest.raises(ValueError):
         P.PackedFrames.load(str(bad))
+    # interior damage: first and last offset intact, one in the middle not; and a header that contradicts its payload
+    good = P.PackedFrames.load(paths["P0"], mmap=False)
+    for what in ("offset", "header"):
+        offs, hdrs = good.offsets.copy(), good.headers.copy()
+        if what == "offset":
+            offs[3], offs[4] = offs[4], offs[3]
+        else:
+            hdrs[2, 4] += 1
+        dmg = tmp_path / f"dmg_{what}.tsdfpk"
+        P.PackedFrames(good.depth, good.offsets, good.headers, good.gt, good.group_start, good.group_names).save(str(dmg))
+        blob = bytearray(open(dmg, "rb").read())
+        pos = 64                                                   # headers, then offsets (64-byte aligned sections)
+        blob[pos:pos + hdrs.nbytes] = hdrs.tobytes()
+        pos = (pos + hdrs.nbytes + 63) // 64 * 64
+        blob[pos:pos + offs.nbytes] = offs.tobytes()
+        open(dmg, "wb").write(bytes(blob))
+        with pytest.raises(ValueError):
+            P.PackedFrames.load(str(dmg))
     with open(tmp_path / "db" / "P0" / "1" / "000001_depth.bin", "ab") as f:
         f.write(b"\0\0\0\0")
     with pytest.raises(ValueError):
@@ -341,6 +359,47 @@ def test_plan_batches_contiguous_rank_shards(pkg):
     assert len(pb(130, 64, drop_last=True)) == 2 and len(pb(130, 64)) == 3
 
 
+def test_training_loaders_give_every_rank_the_same_number_of_batches(pkg, synth):
+    """a training loop that steps a gradient collective once per batch hangs when ranks run out of
+    batches at different times.  With MSRA-like crop areas (3x apart between subjects) a pixel-balanced split of 8 ranks
+    gives 7 to 15 batches of 1024; the loaders therefore split by FRAME COUNT by default and pad the one rank that
+    can come up a batch short; balance="pixels" stays available for export jobs."""
+    pb = pkg.dataset.plan_batches
+    rng = np.random.default_rng(5)
+    # nine "subjects" of 8,500 frames whose crops differ ~3x in area
+    w = np.concatenate([rng.integers(int(a * 0.9), int(a * 1.1), 8500) for a in rng.uniform(8000, 26000, 9)])
+    n = w.size
+    by_px = [len(pb(n, 1024, rank=r, world=8, weights=w)) for r in range(8)]
+    assert max(by_px) > min(by_px) + 1                      # the hazard is real
+    for world, bs, drop in ((8, 1024, False), (8, 1024, True), (3, 16, False), (7, 64, True), (8, 100, False)):
+        plans = [pb(n, bs, rank=r, world=world, shuffle=True, seed=1, epoch=2, drop_last=drop) for r in range(world)]
+        assert len({len(p) for p in plans}) == 1, (world, bs, drop)
+        flat = np.concatenate([np.concatenate(p) for p in plans])
+        if drop:
+            assert len(set(flat.tolist())) == flat.size and all(b.size == bs for p in plans for b in p)
+        else:
+            assert set(flat.tolist()) == set(range(n))      # everything is seen; at most one repeat per rank (the pad)
+            assert flat.size - n <= world
+    # the one-frame-short case: 2 ranks, 7 frames, batches of 3 -> shards 3 / 4 -> 1 / 2 batches -> padded to 2 / 2
+    p0, p1 = pb(7, 3, rank=0, world=2), pb(7, 3, rank=1, world=2)
+    assert [b.tolist() for b in p0] == [[0, 1, 2], [0]] and [b.tolist() for b in p1] == [[3, 4, 5], [6]]
+    # the loaders: __len__ is planned on the host (no GPU needed) and agrees across ranks by default
+    frames = [synth.synth_frame(900 + i, "crop") for i in range(37)]
+    pk = pkg.packing.pack_frames(frames)
+    pk.gt = np.zeros((37, 63), np.float32)
+    ds = pkg.MSRADepthDataset.from_packs([pk])
+    for cls in (pkg.VoxelLoader, pkg.ResidentLoader):
+        lens = [len(cls(ds, batch_size=4, device="cuda", rank=r, world=4)) for r in range(4)]
+        assert len(set(lens)) == 1 and lens[0] == 3, (cls.__name__, lens)
+        px = [sum(b.size for b in cls(ds, batch_size=4, device="cuda", rank=r, world=4, balance="pixels")._batches())
+              for r in range(4)]
+        assert sum(px) == 37
+    with pytest.raises(ValueError):
+        pb(10, 2, balance="pixels")
+    with pytest.raises(ValueError):
+        pb(10, 2, balance="bytes")
+
+
 def test_gt_3d_export_round_trips_through_the_reference_reader(pkg, tmp_path):
     """export.write_gesture(gt_3d=True) stores z negated; the reference reader's branch for 3-D label arrays
     (3D_CNN/dataset.py:107-109: negate z, reshape to [n,63]) then gives back the camera-frame labels."""
@@ -385,3 +444,22 @@ def test_native_gather_equals_numpy_gather(pkg):
     assert L.tsdf_host_gather_frames(*args(bad, buf.size)) == -1
     assert L.tsdf_host_gather_frames(*args(np.array([0, 1], np.int64), 1)) == -1
     assert L.tsdf_host_gather_frames(*args(np.array([5, 5], np.int64), buf.size)) == 0 and off2[2] == 2 * frames[5][1].size
+    # ABI v5: the entry that knows the source's length refuses offsets that leave it, or that run backwards (a damaged
+    # pack), before copying anything — the v4 entry could only trust them
+    args_n = lambda offs, ix, src_len: (pk.depth.ctypes.data, src_len, offs.ctypes.data, 60, ix.ctypes.data, ix.size,
+                                        buf.ctypes.data, buf.size, off2.ctypes.data, 4)
+    two = np.array([5, 59], np.int64)
+    assert L.tsdf_host_gather_frames_n(*args_n(pk.offsets, two, pk.depth.size)) == 0
+    assert L.tsdf_host_gather_frames_n(*args_n(pk.offsets, two, pk.depth.size - 1)) == -1     # last frame leaves the buffer
+    assert L.tsdf_host_gather_frames_n(*args_n(pk.offsets, two, -5)) == -1
+    broken = pk.offsets.copy()
+    broken[6] = broken[5] - 3                                                                 # frame 5 runs backwards
+    assert L.tsdf_host_gather_frames_n(*args_n(broken, two, pk.depth.size)) == -1
+    assert L.tsdf_host_gather_frames(pk.depth.ctypes.data, broken.ctypes.data, 60, two.ctypes.data, 2, buf.ctypes.data,
+                                     buf.size, off2.ctypes.data, 4) == -1
+    broken = pk.offsets.copy()
+    broken[5] = -1
+    assert L.tsdf_host_gather_frames_n(*args_n(broken, np.array([5, 4], np.int64), pk.depth.size)) == -1
+    bad_pk = packing.PackedFrames(pk.depth, broken, pk.headers)
+    with pytest.raises(ValueError):
+        bad_pk.take(np.array([9, 5, 4, 7, 1], np.int64))

@@ -1195,6 +1195,81 @@ def test_resident_loader(pkg, synth):
     assert b.resident_bytes() == sum(4 * f[1].size for f in frames)
 
 
+def test_resident_loader_prefetch_ring(pkg, synth):
+    """ResidentLoader(prefetch=k): one launch voxelizes k batches into a ring and the loader yields views of it — the
+    reference's batch size (16, 3D_CNN/train.py:36) without the host in the step.  Same frames, same order, same bits as
+    prefetch=1 (plain and augmented, ragged last block, ring wrapped several times, two ranks); a batch's tensors are
+    recycled only after (ring-1)*k further batches."""
+    d = dev()
+    frames = [synth.synth_frame(7100 + i, "crop") for i in range(150)]
+    pk = pkg.packing.pack_frames(frames)
+    pk.gt = np.random.default_rng(4).normal(0, 70, (150, 63)).astype(np.float32)
+    ds = pkg.MSRADepthDataset.from_packs([pk])
+    for kw in (dict(), dict(augment=True, res=16), dict(rank=1, world=2), dict(drop_last=True), dict(labels=False)):
+        base = dict(batch_size=16, device=d, shuffle=True, seed=6)
+        base.update(kw)
+        one = pkg.ResidentLoader(ds, **base)
+        ring = pkg.ResidentLoader(ds, prefetch=3, ring=2, **base)      # 48 frames per launch: 150 -> 3 full blocks + 6
+        assert len(one) == len(ring)
+        for epoch in range(2):
+            held = []
+            nb = 0
+            for x, y in zip(one, ring):
+                torch.cuda.synchronize()
+                for u, v in zip(x, y):
+                    assert (u is None and v is None) or torch.equal(u, v)
+                held.append((nb, y.tsdf, x.tsdf.clone()))
+                nb += 1
+                # still intact while fewer than (ring-1)*k = 3 further batches have been drawn
+                for when, view, want in held[-3:]:
+                    assert torch.equal(view, want), (when, nb)
+            assert nb == len(one)
+    # the fused-kernel regime: 64 batches of 16 per launch
+    big = pkg.ResidentLoader(ds, batch_size=2, device=d, shuffle=True, seed=1, prefetch=64)
+    ref = pkg.ResidentLoader(ds, batch_size=2, device=d, shuffle=True, seed=1)
+    for x, y in zip(ref, big):
+        assert torch.equal(x.tsdf, y.tsdf) and torch.equal(x.gt_nor, y.gt_nor) and torch.equal(x.status, y.status)
+    with pytest.raises(ValueError):
+        pkg.ResidentLoader(ds, batch_size=2, device=d, prefetch=0)
+
+
+def test_msra_dataset_prebatched_under_the_reference_loader_call(pkg, synth):
+    """DataLoader(MSRA_Dataset(...), batch_size=16, shuffle=True) — 3D_CNN/train.py:36,86-91 — on a resident dataset:
+    __getitems__ returns the batch already batched (PreBatched, unwrapped by torch's default_collate), outputs in a
+    recycled ring.  Equal to the item-tuple path batch for batch, across several turns of a small ring, with a ragged
+    last batch; single items are clones that outlive the ring."""
+    d = dev()
+    frames = [synth.synth_frame(7300 + i, "crop") for i in range(205)]
+    pk = pkg.packing.pack_frames(frames)
+    pk.gt = np.random.default_rng(5).normal(0, 70, (205, 63)).astype(np.float32)
+    raw = pkg.MSRADepthDataset.from_packs([pk])
+    fast = pkg.MSRA_Dataset.from_raw(raw, device=d, ring=16)
+    slow = pkg.MSRA_Dataset.from_raw(raw, device=d, prebatched=False)
+    assert fast.prebatched and fast.resident and not slow.prebatched
+    DL = torch.utils.data.DataLoader
+    for epoch in range(3):          # 13 batches per epoch, ring of 16: wraps in the second epoch
+        a = DL(fast, batch_size=16, shuffle=True, generator=torch.Generator().manual_seed(epoch))
+        b = DL(slow, batch_size=16, shuffle=True, generator=torch.Generator().manual_seed(epoch))
+        nb = 0
+        for (t1, g1, l1, m1), (t2, g2, l2, m2) in zip(a, b):
+            assert t1.is_cuda and t1.shape[1:] == (3, 32, 32, 32) and g1.shape[1:] == (63,)
+            assert torch.equal(t1, t2) and torch.equal(g1, g2) and torch.equal(l1, l2) and torch.equal(m1, m2)
+            nb += 1
+        assert nb == 13
+    ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32, n_threads=8)
+    one = fast[77]
+    for _ in DL(fast, batch_size=16):   # a whole epoch later the item is still what it was
+        pass
+    torch.cuda.synchronize()
+    assert np.abs(one[0].cpu().numpy() - ref["tsdf"][77]).max() <= TOL and float(one[2]) == ref["max_l"][77]
+    np.testing.assert_array_equal(one[1].cpu().numpy(), pk.gt[77])
+    with pytest.raises(IndexError):
+        fast.__getitems__([3, 205])
+    # a larger batch than the ring was built for: the ring is rebuilt
+    (t, g, l, m), = list(DL(fast, batch_size=205))
+    assert np.abs(t.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
 def test_indexed_batches_with_fused_augmentation(pkg, synth):
     """tsdf_voxelize_indexed_aug_hip: index + per-batch-position maps == tsdf_voxelize_aug_labels_hip on the gathered
     frames, bit for bit (fused and split kernels); ResidentLoader(augment=True) draws reference-distribution maps about

@@ -57,7 +57,9 @@ def _frame(seed, bw, bh, l, t, valid_frac, near):
 frames = st.builds(_frame, seed=st.integers(0, 2 ** 31 - 1), bw=st.integers(3, 48), bh=st.integers(3, 40),
                    l=st.integers(0, 200), t=st.integers(0, 150), valid_frac=st.floats(0.1, 0.6),
                    near=st.floats(200.0, 900.0))
-prop = settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+# derandomize: the same examples on every run (the driver's CPU tier must not depend on a random seed or a local database)
+prop = settings(max_examples=60, deadline=None, derandomize=True, database=None,
+                suppress_health_check=[HealthCheck.too_slow])
 
 
 @prop
@@ -80,7 +82,7 @@ def test_property_range_sign_and_zero_mask(fr, R):
     assert (neg[:, acc] == neg[0][acc]).all()          # shared sign where the voxel was accepted
     far = (np.abs(v) == 1).all(axis=0)
     assert ((np.abs(v[:, far]) == 1).all())
-    assert acc.any()                                    # a frame with valid pixels produces some surface
+    # (no claim that some voxel is accepted: a 3-pixel-wide box under an 8^3 grid can miss every voxel centre)
 
 
 @prop

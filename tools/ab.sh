@@ -3,7 +3,7 @@
 for rep in 1 2; do
 for lib in "$@"; do
   echo "== $lib (round $rep)"
-  if [ "$lib" = default ]; then unset TSDF_HIP_LIB; else export TSDF_HIP_LIB=$PWD/handposeestimation-with-3d-cnns_amd/$lib; fi
+  if [ "$lib" = default ]; then unset TSDF_HIP_LIB; else export TSDF_ALLOW_LIB_OVERRIDE=1 TSDF_HIP_LIB=$PWD/build/$lib; fi
   python3 tools/exp_scale.py 2>&1 | grep "n="
 done
 done

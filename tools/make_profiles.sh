@@ -32,7 +32,7 @@ echo "--- crops"
 PMC_MODE=crop rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/crop_trace -- python3 tools/exp_pmc.py > $OUT/crop_trace.log 2>&1 || tail -3 $OUT/crop_trace.log
 PMC_MODE=crop rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/crop_fetch -- python3 tools/exp_pmc.py > $OUT/crop_fetch.log 2>&1 || tail -3 $OUT/crop_fetch.log
 PMC_MODE=crop rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/crop_write -- python3 tools/exp_pmc.py > $OUT/crop_write.log 2>&1 || tail -3 $OUT/crop_write.log
-if [ -f handposeestimation-with-3d-cnns_amd/libtsdf_hip_cap.so ]; then
+if [ -f build/libtsdf_hip_cap.so ]; then
   echo "--- TSDF_FILL A/B"
   for cfg in "full 1024" "full 4096" "crop 1024" "crop 4096"; do set -- $cfg
     PROF_KIND=$1 PROF_N=$2 AB_BLOCKS=12 python3 tools/ab_precise.py libtsdf_hip.so libtsdf_hip_cap.so 2>&1 | grep -v amdgpu.ids

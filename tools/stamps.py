@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase timeline of the fused kernel from in-kernel stamps (diagnostic library only).
 
-Build:  make -C handposeestimation-with-3d-cnns_amd/csrc stamps     (libtsdf_hip_stamps.so)
+Build:  make -C handposeestimation-with-3d-cnns_amd/csrc stamps     (build/libtsdf_hip_stamps.so)
 Run on the GPU box:  python tools/stamps.py
 Slots: 0 frame start | 1 rows streamed | 2 row/column extremes back-projected | 3 wave partials in LDS
        4 AABB known (after barrier + final reduce + glue) | 5 z table | 6 projection tables
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
 # the diagnostic library is loaded directly (any ABI version: only tsdf_voxelize_hip is called)
-L = ctypes.CDLL(os.environ.get("STAMPS_LIB") or os.path.join(ROOT, "handposeestimation-with-3d-cnns_amd", "libtsdf_hip_stamps.so"))
+L = ctypes.CDLL(os.environ.get("STAMPS_LIB") or os.path.join(ROOT, "build", "libtsdf_hip_stamps.so"))
 vp = ctypes.c_void_p
 L.tsdf_voxelize_hip.restype = ctypes.c_int
 L.tsdf_voxelize_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, vp]

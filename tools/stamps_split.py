@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
-L = ctypes.CDLL(os.path.join(ROOT, "handposeestimation-with-3d-cnns_amd", "libtsdf_hip_stamps.so"))
+L = ctypes.CDLL(os.path.join(ROOT, "build", "libtsdf_hip_stamps.so"))
 vp = ctypes.c_void_p
 L.tsdf_voxelize_hip.restype = ctypes.c_int
 L.tsdf_voxelize_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, vp]

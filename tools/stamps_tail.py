@@ -10,7 +10,8 @@ import ctypes, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("TSDF_HIP_LIB", os.path.join(ROOT, "handposeestimation-with-3d-cnns_amd", "libtsdf_hip_stamps.so"))
+os.environ.setdefault("TSDF_HIP_LIB", os.path.join(ROOT, "build", "libtsdf_hip_stamps.so"))
+os.environ.setdefault("TSDF_ALLOW_LIB_OVERRIDE", "1")
 pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
 synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
 L = pkg._lib.load()
