@@ -139,7 +139,7 @@ def gpu_topology(sysfs: str = "/sys", env=None):
         try:
             props = dict(ln.split()[:2] for ln in open(os.path.join(base, str(nd), "properties")) if len(ln.split()) >= 2)
         except OSError:
-            return []
+            continue      # a GPU of the host that this container may not open (device cgroup): HIP does not enumerate it either
         if int(props.get("simd_count", "0")) <= 0:
             continue      # a CPU node
         loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
@@ -892,7 +892,7 @@ def main():
                                   "not measured in this run",
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                 "working_set_bytes": abytes,
-                "kernel": "tsdf_fused_kernel<32, 0, false, false>", "algorithmic_bytes_per_launch": abytes,
+                "kernel": "tsdf_fused_kernel<32, 0, false, false, 2>", "algorithmic_bytes_per_launch": abytes,
                 "launch_ms_mean": round(mean_ms, 4),
                 "single_launch_ms_median": round(float(np.median(kern_ms)), 4),
                 "single_launch_ms_min": round(float(kern_ms.min()), 4),

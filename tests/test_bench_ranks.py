@@ -68,6 +68,15 @@ def test_affinity_plan_on_an_eight_gpu_two_socket_node(tmp_path):
         == ["0000:65:00.0"]
     assert b.gpu_topology(str(tmp_path), env={"HIP_VISIBLE_DEVICES": "GPU-deadbeef"}) == []
     assert b.gpu_topology(str(tmp_path / "nothing"), env={}) == []
+    # a one-GPU container on that host: the other GPUs' nodes are listed but may not be opened (seen on the GPU box:
+    # "Operation not permitted") — they are skipped, as HIP skips them
+    import shutil
+    for k in (2, 3, 4, 6, 7, 8, 9):
+        f = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes" / str(k) / "properties"
+        os.remove(f)
+        os.mkdir(f)          # opening it now fails with an OSError, whoever runs the test
+    one = b.gpu_topology(str(tmp_path), env={})
+    assert [t[0] for t in one] == ["0000:35:00.0"] and one[0][1] == 0
     assert b._format_cpulist({0, 1, 2, 5, 7, 8}) == "0-2,5,7-8" and b._parse_cpulist("0-2,5,7-8\n") == {0, 1, 2, 5, 7, 8}
 
 

@@ -25,7 +25,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "tsdf_fused_kernel<32, 0, false, false>"
+KERNEL = "tsdf_fused_kernel<32, 0, false, false"   # (prefix: the group count follows as a fifth template argument)
 
 
 def counter_medians(d):
@@ -112,7 +112,7 @@ def collect(out, tag):
                 w.writeheader()
                 for r in rows:
                     w.writerow({k: r[k] for k in keep})
-    for sub in ("aug64/trace", "crop_trace"):
+    for sub in ("aug64/trace", "crop_trace", "r64_trace"):
         for f in sorted(glob.glob(os.path.join(out, sub, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             shutil.copy(f, os.path.join(dst, sub.split("/")[0] + "_kernel_stats.csv"))
     for sub in ("aug64/sq_a", "aug64/sq_b", "aug64/sq_c", "crop_fetch", "crop_write"):

@@ -17,8 +17,9 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
-BENCH="python3 bench.py --steps 50 --warmup 5 --no-extras"
-python3 bench.py --steps 50 --warmup 5 > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
+# (a step is 16 launches: 6 steps + 1 warm-up + the 50 single launches of the spread pass = 162 launches per pass)
+BENCH="python3 bench.py --steps 6 --warmup 1 --no-extras --no-config3"
+python3 bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
 tail -1 $OUT/bench_unprofiled.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
@@ -28,6 +29,8 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 python3 tools/collect_profiles.py $OUT summarize
 echo "--- augmented 64^3"
 tools/gpu_pmc_aug.sh profiles_$TAG/aug64 aug64 > $OUT/aug64.log 2>&1 || tail -3 $OUT/aug64.log
+echo "--- plain 64^3"
+PMC_MODE=r64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r64_trace -- python3 tools/exp_pmc.py > $OUT/r64_trace.log 2>&1 || tail -3 $OUT/r64_trace.log
 echo "--- crops"
 PMC_MODE=crop rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/crop_trace -- python3 tools/exp_pmc.py > $OUT/crop_trace.log 2>&1 || tail -3 $OUT/crop_trace.log
 PMC_MODE=crop rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/crop_fetch -- python3 tools/exp_pmc.py > $OUT/crop_fetch.log 2>&1 || tail -3 $OUT/crop_fetch.log
