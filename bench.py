@@ -718,6 +718,12 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip configs[3]_sharded (every rank, every N)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: everything else that writes to file descriptor 1 during the run — RCCL prints a
+    # five-line version banner there when the first communicator comes up — is sent to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -931,7 +937,8 @@ def main():
         masks = [affinity]
     if rank == 0:
         line["per_rank"]["affinity"] = masks
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
 
     if dist is not None:
         collective_barrier()

@@ -1915,7 +1915,10 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
 // L2 hits).  The mailboxes are a lazily allocated per-stream workspace owned by the library (host: xchg_for());
 // launches that cannot have one (stream capture, too many streams) use the redundant form.
 constexpr int kXchgParts = 16;       // mailboxes per frame (upper bound of a.split)
-constexpr int kXchgFrames = 128;     // frames per split launch at most (n <= CUs/2)
+#ifndef TSDF_XCHG_FRAMES
+#define TSDF_XCHG_FRAMES 128
+#endif
+constexpr int kXchgFrames = TSDF_XCHG_FRAMES;  // frames per split launch at most (n <= CUs/2)
 constexpr int kXchgBox = 16;         // floats per mailbox: 10 extents, tag, pad (64 bytes: one mailbox per line)
 constexpr int kXchgPolls = 4000;     // bound of the wait (x ~0.1 us)
 
