@@ -749,6 +749,19 @@ def main():
     got_pci = be.pci()
     if got_pci and affinity.get("pci"):
         affinity["pci_matches_runtime"] = got_pci[:10] == affinity["pci"][:10]   # domain:bus:device
+        if not affinity["pci_matches_runtime"]:
+            # the runtime enumerates the GPUs in another order than the KFD topology lists them: pin again, late, to the
+            # cores of the GPU this rank really has (its helper threads keep the first mask; better than the wrong node)
+            topo = gpu_topology(os.environ.get("TSDF_BENCH_SYSFS", "/sys"))
+            hit = [i for i, t in enumerate(topo) if t[0][:10] == got_pci[:10]]
+            if hit:
+                try:
+                    cpus = topo[hit[0]][2] & set(os.sched_getaffinity(0)) or topo[hit[0]][2]
+                    os.sched_setaffinity(0, cpus)
+                    affinity.update(repinned=True, cpus=_format_cpulist(os.sched_getaffinity(0)), numa_node=topo[hit[0]][1],
+                                    pci=topo[hit[0]][0])
+                except OSError:
+                    pass
 
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
