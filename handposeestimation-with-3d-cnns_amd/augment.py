@@ -72,6 +72,34 @@ def reference_data_aug(points: np.ndarray, S: np.ndarray, R: np.ndarray) -> np.n
     return (ps - m) @ R + m
 
 
+def draw_params(n: int, rng=None):
+    """The augmentation parameters of n frames with the reference's distributions (pre/process.py:209-216):
+    ``(stretch float64[n], rot_xy int64[n], rot_z int64[n])``.  ``rng``: seed / ``np.random.Generator``; or a legacy
+    ``np.random.RandomState``, in which case every frame takes the reference's own three draws in its order
+    (:func:`reference_draw`)."""
+    if isinstance(rng, np.random.RandomState):
+        draws = [reference_draw(rng) for _ in range(n)]
+        return (np.array([d[0] for d in draws], np.float64), np.array([d[1] for d in draws], np.int64),
+                np.array([d[2] for d in draws], np.int64))
+    rng = np.random.default_rng(rng)
+    return rng.uniform(2 / 3, 3 / 2, n), rng.integers(-30, 30, n), rng.integers(-30, 30, n)
+
+
+def affines_from_params(centres: np.ndarray, stretch, rot_xy, rot_z) -> np.ndarray:
+    """The maps ``T(p) = Rᵀ·S·(p - m) + m`` of the module docstring for centres m [n,3] and per-frame parameters:
+    float64[n,24] (forward rows then inverse rows)."""
+    m = np.asarray(centres, np.float64).reshape(-1, 3)
+    n = m.shape[0]
+    S = np.zeros((n, 3, 3))
+    S[:, 0, 0] = stretch
+    S[:, 1, 1] = stretch
+    S[:, 2, 2] = 1.0
+    Rt = np.swapaxes(rotation_xyz(rot_xy, rot_xy, rot_z), -1, -2)
+    A = Rt @ S
+    b = m - np.einsum("nij,nj->ni", A, m)
+    return pack_affine(A, b)
+
+
 def random_affines(centres: np.ndarray, rng=None):
     """One augmentation per frame with the reference's distributions (pre/process.py:209-216).
 
@@ -81,25 +109,8 @@ def random_affines(centres: np.ndarray, rng=None):
     Returns (xforms float64[n,24], params dict(stretch, rot_xy, rot_z)).
     """
     m = np.asarray(centres, np.float64).reshape(-1, 3)
-    n = m.shape[0]
-    if isinstance(rng, np.random.RandomState):
-        draws = [reference_draw(rng) for _ in range(n)]
-        stretch = np.array([d[0] for d in draws], np.float64)
-        rot_xy = np.array([d[1] for d in draws], np.int64)
-        rot_z = np.array([d[2] for d in draws], np.int64)
-    else:
-        rng = np.random.default_rng(rng)
-        stretch = rng.uniform(2 / 3, 3 / 2, n)
-        rot_xy = rng.integers(-30, 30, n)
-        rot_z = rng.integers(-30, 30, n)
-    S = np.zeros((n, 3, 3))
-    S[:, 0, 0] = stretch
-    S[:, 1, 1] = stretch
-    S[:, 2, 2] = 1.0
-    Rt = np.swapaxes(rotation_xyz(rot_xy, rot_xy, rot_z), -1, -2)
-    A = Rt @ S
-    b = m - np.einsum("nij,nj->ni", A, m)
-    return pack_affine(A, b), dict(stretch=stretch, rot_xy=rot_xy, rot_z=rot_z)
+    stretch, rot_xy, rot_z = draw_params(m.shape[0], rng)
+    return affines_from_params(m, stretch, rot_xy, rot_z), dict(stretch=stretch, rot_xy=rot_xy, rot_z=rot_z)
 
 
 def apply_affine(points: np.ndarray, xforms: np.ndarray) -> np.ndarray:

@@ -646,7 +646,16 @@ class MSRA_Dataset(data.Dataset):
     ``block`` consecutive frames the first time one of them is asked for, and returned as GPU tensors (the
     reference returns numpy rows that its training loop then moves with ``.cuda()``, train.py:200,232).
     ``opt.size`` / ``opt.test_index`` are honoured when present (the reference ignores ``opt`` and hard-codes
-    ``'small'`` / 2, :20-22); ``aug=True`` is rejected like ``DataProcess(aug=True)``: use ``voxelize_aug``.
+    ``'small'`` / 2, :20-22).
+
+    ``aug=True`` (3D_CNN/dataset.py:57-62: "add augmentation dataset") appends an AUGMENTED rendition of every frame the
+    dataset holds: items ``[n, 2n)`` are frames ``[0, n)`` under a fixed per-frame 3-D augmentation, drawn once with the
+    reference's distributions (``augment.draw_params(n, aug_seed)``) about the frame's own un-augmented grid centre and
+    FUSED into the voxelizer (the re-specified contract of ``tsdf_voxelize_aug_hip``; the reference's own ``_aug`` files
+    cannot be produced — ``data_aug`` raises AxisError — and its loader reads the plain files again for them, SURVEY.md
+    App. B#8,#11).  The item's ``gt`` are the joints under the same map, ``max_l`` / ``mid_p`` those of the augmented
+    grid.  With ``aug=True`` every batch goes through the augmented entry — plain items with the identity map, whose
+    volumes equal the plain entry's to the float32 rounding (grid, zero mask, sign and z component bit for bit).
 
     Under the reference's own ``DataLoader(dataset, batch_size=B, shuffle=True)`` (train.py:36,86-91; ``num_workers=0``:
     the items are GPU tensors) the loader hands the batch's indices to :meth:`__getitems__`, which voxelizes exactly
@@ -665,10 +674,9 @@ class MSRA_Dataset(data.Dataset):
 
     def __init__(self, root_path, opt=None, train=True, aug=False, device="cuda", block: int = 1024,
                  packed_dir: Optional[str] = None, resident: Optional[bool] = None, prebatched: Optional[bool] = None,
-                 ring: Optional[int] = None, _raw: Optional[MSRADepthDataset] = None):
-        if aug:
-            raise NotImplementedError("aug=True: the reference loads '_aug' files its preprocessing cannot produce "
-                                      "(data_aug raises AxisError); use voxelize_aug for on-the-fly augmentation")
+                 ring: Optional[int] = None, aug_seed: int = 0, _raw: Optional[MSRADepthDataset] = None):
+        self.AUG = bool(aug)
+        self.aug_seed = aug_seed
         self.size = getattr(opt, "size", "small")
         self.test_idx = int(getattr(opt, "test_index", 2))
         self.PCA_SZ = int(getattr(opt, "PCA_SZ", 63))
@@ -690,6 +698,12 @@ class MSRA_Dataset(data.Dataset):
         self._ring_req = ring
         self._rp: Optional[ResidentPacks] = None
         self._fast = None        # the ring of the pre-batched path (built on the first batch)
+        self._n = len(self.raw)
+        self._aug_params = None  # aug=True: (stretch, rot_xy, rot_z) of every frame, drawn once
+        self._xf_table = None    # ... and, resident, the maps of all 2n items (identity for the first n), float64[2n,24]
+        if self.AUG:
+            from . import augment as _aug
+            self._aug_params = _aug.draw_params(self._n, aug_seed)
 
     @classmethod
     def from_raw(cls, raw: MSRADepthDataset, device="cuda", **kw) -> "MSRA_Dataset":
@@ -697,14 +711,42 @@ class MSRA_Dataset(data.Dataset):
         return cls(None, device=device, _raw=raw, **kw)
 
     def __len__(self):
-        return len(self.raw)
+        return 2 * self._n if self.AUG else self._n
+
+    def _resident_packs(self) -> "ResidentPacks":
+        if self._rp is None:
+            self._rp = ResidentPacks(self.raw, self.device)
+            if self.AUG:   # every frame's own grid centre (one AABB launch over the pack), then all maps at once
+                from . import augment as _aug
+                from .voxelize import aabb
+                rp = self._rp
+                mid = aabb(rp.depth, rp.offsets, rp.headers).grid[:, :3].cpu().numpy().astype(np.float64)[rp.frame]
+                self._xf_table = np.ascontiguousarray(np.concatenate(
+                    [_aug.identity_affines(self._n), _aug.affines_from_params(mid, *self._aug_params)]))
+                self._frame2 = np.ascontiguousarray(np.concatenate([rp.frame, rp.frame]))
+        return self._rp
+
+    def _aug_batch_host_fed(self, idx: np.ndarray):
+        """aug=True on a dataset that is not resident: upload the frames, one AABB launch for their centres, then the
+        augmented entry (identity maps for the plain items)."""
+        from . import augment as _aug
+        from .voxelize import aabb, voxelize_aug
+        src = idx % self._n
+        pk = self.raw.take(src)
+        depth, offsets, headers = pk.to_torch(self.device, pin=False, non_blocking=False)
+        mid = aabb(depth, offsets, headers).grid[:, :3].cpu().numpy().astype(np.float64)
+        st, rxy, rz = (p[src] for p in self._aug_params)
+        xf = _aug.affines_from_params(mid, st, rxy, rz)
+        plain = idx < self._n
+        xf[plain] = _aug.identity_affines(int(plain.sum()))
+        gt = torch.from_numpy(np.ascontiguousarray(pk.gt)).to(self.device)
+        out, _, gt_aug = voxelize_aug(depth, offsets, headers, torch.from_numpy(xf).to(self.device), res=32, gt=gt)
+        return out, gt_aug
 
     def _load_block(self, blk: int):
         a, b = blk * self.block, min(len(self.raw), (blk + 1) * self.block)
         if self.resident:
-            if self._rp is None:
-                self._rp = ResidentPacks(self.raw, self.device)
-            rp = self._rp
+            rp = self._resident_packs()
             self._cache, _, self._cache_gt = voxelize_indexed(
                 rp.depth, rp.offsets, rp.headers, torch.from_numpy(rp.frame[a:b]).to(self.device), rp.gt, gt_copy=True)
         else:
@@ -722,7 +764,7 @@ class MSRA_Dataset(data.Dataset):
 
         kGroup = 16
 
-        def __init__(self, rp: "ResidentPacks", bs: int, ring: int, device):
+        def __init__(self, rp: "ResidentPacks", bs: int, ring: int, device, frame=None, xf_table=None):
             import ctypes
             from . import _lib
             ring = -(-ring // self.kGroup) * self.kGroup
@@ -756,9 +798,17 @@ class MSRA_Dataset(data.Dataset):
                 (lambda i: torch.cuda.current_stream(i).cuda_stream)
             self.cur_dev = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
             self.fn = self.L.tsdf_voxelize_indexed_hip
-            self.take = rp.frame.take                     # dataset item -> frame of the resident packs
+            self.take = (rp.frame if frame is None else frame).take   # dataset item -> frame of the resident packs
             self.rows = [self.h_idx_np[k] for k in range(ring)]
             assert self.kGroup == 16
+            self.xf_take = None
+            if xf_table is not None:   # aug=True: one map per batch position, in page-locked memory the kernel reads
+                self.fn_aug = self.L.tsdf_voxelize_indexed_aug_hip
+                self.h_xf = torch.empty((ring, bs, 24), dtype=torch.float64).pin_memory()
+                self.h_xf_np = self.h_xf.numpy()
+                self.xf_rows = [self.h_xf_np[k] for k in range(ring)]
+                self.xf_ptr = [self.h_xf[k].data_ptr() for k in range(ring)]
+                self.xf_take = xf_table.take
 
     def _fast_batch(self, indices):
         """One batch through the ring: ~4 us of Python around the C call (the HIP launch itself is the larger part)."""
@@ -767,7 +817,8 @@ class MSRA_Dataset(data.Dataset):
         if f is None or n > f.bs:
             vol = n * (3 * 32 ** 3 * 4)
             ring = self._ring_req if self._ring_req else max(16, min(256, (2 << 30) // max(vol, 1)))
-            f = self._fast = MSRA_Dataset._Fast(self._rp, n, ring, self.device)
+            f = self._fast = MSRA_Dataset._Fast(self._rp, n, ring, self.device,
+                                                frame=self._frame2 if self.AUG else None, xf_table=self._xf_table)
         k = f.slot
         within = k & (f.kGroup - 1)
         if within == 0 and f.read_used[k >> 4]:
@@ -779,7 +830,15 @@ class MSRA_Dataset(data.Dataset):
         else:
             f.h_idx_np[k, :n] = f.take(indices)
         a = f.args[k]
-        if f.cur_dev() == f.dev_index:
+        if f.xf_take is not None:     # aug=True: the batch's maps next to its indices
+            if n == f.bs:
+                f.xf_take(indices, axis=0, out=f.xf_rows[k])
+            else:
+                f.h_xf_np[k, :n] = f.xf_take(indices, axis=0)
+            with torch.cuda.device(f.device):
+                rc = f.fn_aug(*f.head, a[0], n, 32, None, 0, f.raw_stream(f.dev_index), f.xf_ptr[k], a[1], a[2], a[3],
+                              a[4], a[5])
+        elif f.cur_dev() == f.dev_index:
             rc = f.fn(*f.head, a[0], n, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
         else:
             with torch.cuda.device(f.device):
@@ -802,17 +861,27 @@ class MSRA_Dataset(data.Dataset):
         if data.get_worker_info() is not None:
             raise RuntimeError("MSRA_Dataset produces its items on the GPU: use it with num_workers=0 (the reference's "
                                "default, train.py:38), there is nothing for loader processes to do")
-        if self.resident and self._rp is None:
-            self._rp = ResidentPacks(self.raw, self.device)
+        if self.resident:
+            self._resident_packs()
         if self.prebatched:
             if not indices:
                 raise IndexError("empty batch")
             self._last = indices[-1]
             return self._fast_batch(indices)
         idx = np.asarray([int(i) for i in indices], np.int64)
-        if idx.size and (idx.min() < 0 or idx.max() >= len(self.raw)):
-            raise IndexError(int(idx.max() if idx.max() >= len(self.raw) else idx.min()))
+        if idx.size and (idx.min() < 0 or idx.max() >= len(self)):
+            raise IndexError(int(idx.max() if idx.max() >= len(self) else idx.min()))
         self._last = int(idx[-1]) if idx.size else self._last
+        if self.AUG:
+            if self.resident:
+                rp = self._rp
+                xf = torch.from_numpy(self._xf_table[idx]).to(self.device)
+                out, _, gt = voxelize_indexed(rp.depth, rp.offsets, rp.headers,
+                                              torch.from_numpy(self._frame2[idx]).to(self.device), rp.gt, gt_copy=True,
+                                              xforms=xf)
+            else:
+                out, gt = self._aug_batch_host_fed(idx)
+            return [(out.tsdf[k], gt[k], out.max_l[k], out.mid_p[k]) for k in range(idx.size)]
         if self.resident:
             rp = self._rp
             out, _, gt = voxelize_indexed(rp.depth, rp.offsets, rp.headers,
@@ -834,8 +903,11 @@ class MSRA_Dataset(data.Dataset):
 
     def __getitem__(self, index):
         index = int(index)
-        if not 0 <= index < len(self.raw):
+        if not 0 <= index < len(self):
             raise IndexError(index)
+        if self.AUG:                                              # (no block cache: plain and augmented items mix)
+            self._last = index
+            return self._items_of([index])[0]
         blk = index // self.block
         if blk != self._cache_block:
             if index != self._last + 1 and index % self.block:   # random access: this frame alone

@@ -211,7 +211,7 @@ def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.
     out = _make_out(out, n, R, dev)
     lab = gt_nor = gt_dev = None
     if xforms is not None:
-        _dev_check("xforms", xforms, torch.float64, dev)
+        _dev_check("xforms", xforms, torch.float64, dev, host_ok=True)   # (page-locked host memory: read over the link)
         if xforms.numel() != 24 * n:
             raise ValueError("xforms must have shape [n, 24] (forward rows then inverse rows)")
     if gt is not None:

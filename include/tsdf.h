@@ -267,8 +267,10 @@ int tsdf_voxelize_indexed_hip(const float *d_depth, int64_t depth_len, const int
                               const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf, float *d_out_max_l,
                               float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels);
 
-/* The same with the 3-D augmentation of tsdf_voxelize_aug_hip: d_xforms float64[n][24] (device memory) holds one map per
- * BATCH position; labels (may be NULL) are those of the pack, mapped and normalised as by tsdf_voxelize_aug_labels_hip. */
+/* The same with the 3-D augmentation of tsdf_voxelize_aug_hip: d_xforms float64[n][24] holds one map per BATCH position
+ * (device memory, or — like the index — page-locked host memory: a frame's 24 words are read a few times per workgroup, so a
+ * loader that draws its batches by index can keep the maps next to the indices and upload nothing); labels (may be NULL)
+ * are those of the pack, mapped and normalised as by tsdf_voxelize_aug_labels_hip. */
 int tsdf_voxelize_indexed_aug_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
                                   const int32_t *d_headers, int64_t n_pack, const int64_t *d_index, int n, int R,
                                   const tsdf_cam *cam, int layout, void *hip_stream, const double *d_xforms,

@@ -129,7 +129,7 @@ def test_entry_points_fail_loudly_without_a_gpu(pkg, synth):
         pkg.tsdf_f({"header": h, "depth": d}, np.array([[0, 0, -400.0], [50, 60, -300.0]]))
     with pytest.raises(ValueError, match="no CPU path"):
         pkg.voxelize(torch.from_numpy(d), torch.tensor([0, d.size]), torch.from_numpy(h[None]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         pkg.DataProcess({"header": h, "depth": d}, np.zeros(63), aug=True).process()
 
 

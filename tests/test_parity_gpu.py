@@ -414,8 +414,8 @@ def test_on_the_fly_loader_end_to_end(pkg, synth, tmp_path):
             torch.utils.data.DataLoader(res_ds, batch_size=3, shuffle=True, generator=torch.Generator().manual_seed(8)),
             torch.utils.data.DataLoader(rds, batch_size=3, shuffle=True, generator=torch.Generator().manual_seed(8))):
         assert torch.equal(t1, t2) and torch.equal(g1, g2) and torch.equal(l1, l2) and torch.equal(m1, m2)
-    with pytest.raises(NotImplementedError):
-        pkg.MSRA_Dataset(str(tmp_path), Opt(), aug=True)
+    # aug=True no longer raises: see test_aug_true_on_the_reference_entry_points
+    assert len(pkg.MSRA_Dataset(str(tmp_path), Opt(), aug=True)) == 16
 
 
 def test_offline_export_on_the_gpu(pkg, synth, tmp_path):
@@ -1268,6 +1268,106 @@ def test_msra_dataset_prebatched_under_the_reference_loader_call(pkg, synth):
     # a larger batch than the ring was built for: the ring is rebuilt
     (t, g, l, m), = list(DL(fast, batch_size=205))
     assert np.abs(t.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
+def test_aug_true_on_the_reference_entry_points(pkg, synth, tmp_path):
+    """aug=True where the reference crashes (data_aug raises AxisError; its '_aug' files cannot be produced): re-specified,
+    parity unpinned, checked against the oracle's restatement of the augmented contract and by construction.
+    DataProcess(aug=True).process() -> the reference's nine entries (pre/process.py:23-24) with the reference's draws in
+    its order from np.random; MSRA_Dataset(aug=True) (3D_CNN/dataset.py:57-62) -> n plain items followed by n augmented
+    renditions, resident (pre-batched and item-tuple paths, under the reference's DataLoader call) and host-fed."""
+    d = dev()
+    # ---- DataProcess
+    h, dep = synth.synth_frame(4242, "crop")
+    gt = (np.random.default_rng(1).normal(0, 40, (21, 3)) + [0, 0, -420]).astype(np.float32).reshape(63)
+    dp = pkg.DataProcess({"header": h, "depth": dep}, gt, aug=True)
+    np.random.seed(77)
+    res = dp.process()
+    assert len(res) == 9
+    pc, tsdf, max_l, mid_p, pc_aug, tsdf_aug, max_l_aug, mid_p_aug, gt_aug = res
+    assert pc.shape == (6000, 3) and pc_aug.shape == (6000, 3) and gt_aug.shape == (1, 63)
+    assert tsdf_aug.shape == (3, 32, 32, 32) and tsdf_aug.dtype == np.float64 and isinstance(max_l_aug, np.float32)
+    # the draws are the reference's, in its order, from the legacy generator: the resample of 6000 points first
+    # (pre/process.py:16), then uniform / randint / randint (:209,215,216)
+    rs = np.random.RandomState(77)
+    n_pts = dp.point_cloud().shape[0]
+    rs.randint(0, n_pts, size=6000 - n_pts if n_pts < 6000 else 6000)
+    st, rxy, rz = pkg.augment.reference_draw(rs)
+    want_xf = pkg.augment.affines_from_params(np.asarray(mid_p, np.float64)[None], [st], [rxy], [rz])
+    np.testing.assert_array_equal(dp.xform, want_xf[0])
+    np.testing.assert_allclose(gt_aug.reshape(21, 3), pkg.augment.apply_affine(gt.reshape(1, 21, 3).astype(np.float64), want_xf)[0],
+                               atol=1e-9)
+    ref = oracle.voxelize_aug(dep, np.array([0, dep.size], np.int64), h[None], want_xf, R=32, layout=1)
+    assert np.abs(tsdf_aug - ref["tsdf"][0]).max() <= TOL and max_l_aug == ref["max_l"][0]
+    np.testing.assert_array_equal(mid_p_aug, ref["mid_p"][0])
+    # ---- MSRA_Dataset, resident
+    frames = [synth.synth_frame(7500 + i, "crop") for i in range(37)]
+    pk = pkg.packing.pack_frames(frames)
+    pk.gt = (np.random.default_rng(6).normal(0, 50, (37, 21, 3)) + [0, 0, -400]).astype(np.float32).reshape(37, 63)
+    raw = pkg.MSRADepthDataset.from_packs([pk])
+    plain = pkg.MSRA_Dataset.from_raw(raw, device=d)
+    aug = pkg.MSRA_Dataset.from_raw(raw, device=d, aug=True, aug_seed=3, ring=16)
+    slow = pkg.MSRA_Dataset.from_raw(raw, device=d, aug=True, aug_seed=3, prebatched=False)
+    assert len(plain) == 37 and len(aug) == 74 and aug.AUG
+    base = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32, n_threads=8)
+    st, rxy, rz = pkg.augment.draw_params(37, 3)
+    xf = pkg.augment.affines_from_params(base["mid_p"].astype(np.float64), st, rxy, rz)
+    want = oracle.voxelize_aug(pk.depth, pk.offsets, pk.headers, xf, R=32, n_threads=8)
+    want_gt = oracle.transform_joints(pk.gt, xf)
+    seen = np.zeros(74, int)
+    DL = torch.utils.data.DataLoader
+    key = {float(v): i for i, v in enumerate(np.concatenate([base["max_l"], want["max_l"]]))}   # item <- its grid's edge
+    assert len(key) == 74
+    for ds in (aug, slow):
+        pos = 0
+        for tsdf, gt_b, max_l, mid_p in DL(ds, batch_size=16, shuffle=True, generator=torch.Generator().manual_seed(2)):
+            torch.cuda.synchronize()
+            for k in range(tsdf.shape[0]):
+                i = key[float(max_l[k])]
+                pos += 1
+                seen[i] += 1
+                if i < 37:      # a plain item through the augmented entry with the identity map
+                    assert np.abs(tsdf[k].cpu().numpy() - base["tsdf"][i]).max() <= 1e-6
+                    np.testing.assert_array_equal(tsdf[k, 2].cpu().numpy(), base["tsdf"][i, 2])          # z: bit for bit
+                    np.testing.assert_array_equal(mid_p[k].cpu().numpy(), base["mid_p"][i])
+                    np.testing.assert_array_equal(gt_b[k].cpu().numpy(), pk.gt[i])
+                else:
+                    f = i - 37
+                    assert np.abs(tsdf[k].cpu().numpy() - want["tsdf"][f]).max() <= TOL
+                    np.testing.assert_array_equal(mid_p[k].cpu().numpy(), want["mid_p"][f])
+                    np.testing.assert_array_equal(gt_b[k].cpu().numpy(), want_gt[f])
+        assert pos == 74
+    assert (seen == 2).all()
+    one = aug[37 + 5]
+    assert np.abs(one[0].cpu().numpy() - want["tsdf"][5]).max() <= TOL
+    with pytest.raises(IndexError):
+        aug[74]
+    # ---- MSRA_Dataset on the raw tree (host-fed): same items
+    for k, (hh, dd) in enumerate(frames[:6]):
+        os.makedirs(tmp_path / "P0" / "1", exist_ok=True)
+        pkg.packing.write_bin(str(tmp_path / "P0" / "1" / ("%06d_depth.bin" % k)), hh, dd)
+    with open(tmp_path / "P0" / "1" / "joint.txt", "w") as fjt:
+        fjt.write("6\n")
+        for k in range(6):
+            fjt.write(" ".join("%.6f" % v for v in pk.gt[k]) + "\n")
+    for sub in ("P1", "P2"):
+        os.makedirs(tmp_path / sub / "1", exist_ok=True)
+        open(tmp_path / sub / "1" / "joint.txt", "w").write("0\n")
+
+    class Opt:
+        size, test_index, PCA_SZ = "small", 0, 63
+    fed = pkg.MSRA_Dataset(str(tmp_path), Opt(), train=False, aug=True, aug_seed=3)
+    assert len(fed) == 12 and not fed.resident
+    st6, rxy6, rz6 = pkg.augment.draw_params(6, 3)
+    xf6 = pkg.augment.affines_from_params(base["mid_p"][:6].astype(np.float64), st6, rxy6, rz6)
+    want6 = oracle.voxelize_aug(pk.depth[: pk.offsets[6]], pk.offsets[:7], pk.headers[:6], xf6, R=32)
+    for i in (7, 2, 11, 6):
+        t = fed[i]
+        if i < 6:
+            assert np.abs(t[0].cpu().numpy() - base["tsdf"][i]).max() <= 1e-6
+        else:
+            assert np.abs(t[0].cpu().numpy() - want6["tsdf"][i - 6]).max() <= TOL
+            assert float(t[2]) == want6["max_l"][i - 6]
 
 
 def test_indexed_batches_with_fused_augmentation(pkg, synth):
