@@ -564,6 +564,13 @@ def extras(pkg, synth, dev, td, to, th, offsets):
         if note:
             ex[name]["what"] = note
         del out
+    # the same kernel on 4096 frames (the 1024 frames four times over): eight frames per half-workgroup instead of two, i.e.
+    # what the launch's tail costs at the BASELINE batch size ("Where the headline launch's time goes")
+    d4 = td.repeat(4)
+    o4 = torch.from_numpy(np.concatenate([offsets[:-1] + k * int(offsets[-1]) for k in range(4)] + [[4 * int(offsets[-1])]])).to(dev)
+    h4 = th.repeat(4, 1)
+    resident("full_4096", d4, o4, h4, RES, 10, o4.cpu().numpy(), note="4096 full 320x240 frames -> 32^3 in one launch")
+    del d4, o4, h4
     resident("full_1024_r64", td, to, th, 64, 10, offsets, note="1024 full 320x240 frames -> 64^3, plain")
     # configs[4]: 64^3 with the fused 3-D augmentation (reference distributions, augment.random_affines)
     mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
