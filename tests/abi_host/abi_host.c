@@ -272,6 +272,22 @@ int main(void) {
     check(tsdf_stream_release(stream) == TSDF_OK && tsdf_stream_release(NULL) == TSDF_OK, "tsdf_stream_release");
   }
 
+  { /* ABI v5: the host-side gather of a shuffled batch, with the length of the source buffer (no GPU involved) */
+    const int64_t pick[3] = {2, 0, 2};
+    int64_t off2[4];
+    float *buf = (float *)malloc((size_t)(2 * (offsets[3] - offsets[2]) + offsets[1]) * sizeof(float));
+    const int64_t cap = 2 * (offsets[3] - offsets[2]) + offsets[1];
+    check(tsdf_host_gather_frames_n(depth, total, offsets, N, pick, 3, buf, cap, off2, 4) == TSDF_OK &&
+              off2[3] == cap && memcmp(buf, depth + offsets[2], (size_t)(offsets[3] - offsets[2]) * 4) == 0 &&
+              memcmp(buf + off2[1], depth, (size_t)offsets[1] * 4) == 0,
+          "tsdf_host_gather_frames_n: frames 2, 0, 2 back to back");
+    check(tsdf_host_gather_frames_n(depth, total - 1, offsets, N, pick, 3, buf, cap, off2, 4) == TSDF_ERR_INVALID_ARG,
+          "  a frame that leaves the source buffer -> TSDF_ERR_INVALID_ARG, nothing copied");
+    check(tsdf_host_gather_frames_n(depth, total, offsets, N, pick, 3, buf, cap - 1, off2, 4) == TSDF_ERR_INVALID_ARG,
+          "  a destination that is too small -> TSDF_ERR_INVALID_ARG");
+    free(buf);
+  }
+
   check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, 0, R, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_OK,
         "n = 0 is a no-op");
   check(tsdf_voxelize_hip(NULL, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s) == TSDF_ERR_INVALID_ARG,
