@@ -259,13 +259,23 @@ struct PixN {
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
 
+#ifndef TSDF_ROW_LOAD_NT
+#define TSDF_ROW_LOAD_NT 0
+#endif
+#ifndef TSDF_DMA_AUX
+#define TSDF_DMA_AUX 0   // cache-policy bits of the staging copy (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 template <int P>
 __device__ __forceinline__ PixN<P> load_pix(const float *__restrict__ p) {
   PixN<P> r;
   constexpr int Q = P / 4, T = P % 4;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
+#if TSDF_ROW_LOAD_NT
+    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p + 4 * q));
+#else
     const f4 v = *reinterpret_cast<const f4u *>(p + 4 * q);
+#endif
     r.d[4 * q] = v.x;
     r.d[4 * q + 1] = v.y;
     r.d[4 * q + 2] = v.z;
@@ -790,10 +800,24 @@ __device__ __forceinline__ unsigned voxel_values4(const int (&ex)[4], const int 
 #endif
 // One 16-byte store of the output volume.  It is written once and never re-read here, so it goes out
 // non-temporal and does not evict the depth rows other workgroups are streaming through L2 / Infinity
-// Cache (measured in round 1: 180 -> 155 us per 1024 frames).
+// Cache (measured in round 1: 180 -> 155 us per 1024 frames; re-checked in round 3: without nt +16 % at 32^3).
+// Round 3: the store also carries DEVICE scope (sc1): it is written through towards memory instead of waiting in
+// this XCD's L2 for a write-back — same-buffer paired A/B, 24 blocks each: 1024 full frames -2.2 % +- 0.2, 1024 crops
+// -1.5 %, 64^3 augmented -1.3 %, 64^3 crops -1.6 % (gpurun_out/ab_store_policy2.log); "sc0 sc1 nt" (system scope) is
+// within noise of it, workgroup scope ("sc0 nt") loses the gain again (+2.7 %), dropping nt costs 16 %.  (Also tried on the
+// read side: nt on the row loads is +12.5 % on full frames — the staging copy's re-read then misses L2 / Infinity Cache,
+// which shows that it normally hits —, nt on the staging copy itself changes nothing; raising the wave priority of either
+// phase with s_setprio costs 3-4 %.)  There is no builtin for the scope bits of a plain store, hence the
+// inline assembly; the s_nop covers the "VALU overwrites the data registers of a wide store" hazard the compiler
+// can no longer see.  -DTSDF_STORE_ASM='"..."' selects other bits; -DTSDF_STORE_BUILTIN the compiler's nt store.
+#ifndef TSDF_STORE_ASM
+#define TSDF_STORE_ASM "sc1 nt"
+#endif
 __device__ __forceinline__ void store_vol4(GlobalOut p, f4 v) {
-#if TSDF_NT_STORE
+#if defined(TSDF_STORE_BUILTIN)
   __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f4 *)p);
+#elif TSDF_NT_STORE
+  asm volatile("global_store_dwordx4 %0, %1, off " TSDF_STORE_ASM "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *(__attribute__((address_space(1))) f4 *)p = v;
 #endif
@@ -1531,7 +1555,7 @@ __device__ __forceinline__ void stage_rect_dma(float *stage, const Frame &f, int
       float *ldst = stage + R0 * sw4;            // wave-uniform LDS base
       if (act && gi + 3 < n_frame) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(f.depth + gi),
-                                         (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)ldst, 16, 0, TSDF_DMA_AUX);
       } else if (act) {  // the 16-byte piece would run past the end of the frame: element copies
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1546,7 +1570,7 @@ __device__ __forceinline__ void stage_rect_dma(float *stage, const Frame &f, int
         float *ldst = stage + row * sw4 + 4 * c4;  // wave-uniform
         if (cg < ng && gi + 3 < n_frame) {
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(f.depth + gi),
-                                           (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+                                           (__attribute__((address_space(3))) void *)ldst, 16, 0, TSDF_DMA_AUX);
         } else if (cg < ng) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
