@@ -861,6 +861,25 @@ class MSRA_Dataset(data.Dataset):
         if data.get_worker_info() is not None:
             raise RuntimeError("MSRA_Dataset produces its items on the GPU: use it with num_workers=0 (the reference's "
                                "default, train.py:38), there is nothing for loader processes to do")
+        f = self._fast
+        if f is not None and f.xf_take is None and len(indices) == f.bs and f.cur_dev() == f.dev_index:
+            # the hot path of a training epoch, inlined (every microsecond here is 6 % of a batch of 16): a full batch of
+            # plain items on the current device — indices into the ring slot, one C call, the slot's prebuilt result
+            k = f.slot
+            if not (k & 15) and f.read_used[k >> 4]:
+                f.read[k >> 4].synchronize()
+            f.take(indices, out=f.rows[k])
+            a = f.args[k]
+            rc = f.fn(*f.head, a[0], f.bs, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
+            if (k & 15) == 15:
+                f.read[k >> 4].record(torch.cuda.current_stream(f.device))
+                f.read_used[k >> 4] = True
+            if rc != 0:
+                from . import _lib
+                _lib.check(rc, "tsdf_voxelize_indexed_hip")
+            f.slot = k + 1 if k + 1 < f.ring else 0
+            self._last = indices[-1]
+            return f.results[k]
         if self.resident:
             self._resident_packs()
         if self.prebatched:
