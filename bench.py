@@ -666,8 +666,8 @@ def extras(pkg, synth, dev, td, to, th, offsets):
         "loader_floor_crops_per_s": round(max(floor[1:])),
         "what": "DataLoader(MSRA_Dataset(...), batch_size=16, shuffle=True) — the reference's training loader call "
                 "(3D_CNN/train.py:36,86-91) — on the resident on-the-fly dataset: every batch is ONE launch issued from "
-                "__getitems__ (indices written to a pinned ring, outputs into a recycled ring, no per-item tensors, "
-                "collation by a registered type).  loader_floor = the same DataLoader call over a dataset whose __getitems__ "
+                "__getitems__ (indices by value inside the kernel arguments, outputs into a recycled ring, no per-item "
+                "tensors, collation by a registered type) and is GPU-bound (tools/exp_dataloader16.py).  loader_floor = the same DataLoader call over a dataset whose __getitems__ "
                 "returns a constant: the cost of torch's sampler / fetcher / iterator machinery on this host, which bounds any "
                 "dataset behind that call"}
     ra = epochs(pkg.ResidentLoader(ds, batch_size=1024, device=dev, shuffle=True, res=64, augment=True), 3)

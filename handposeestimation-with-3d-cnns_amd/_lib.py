@@ -67,6 +67,7 @@ class TsdfLabels(ctypes.Structure):
 
 
 ABI_VERSION = 5
+INLINE_INDEX_MAX = 32   # TSDF_INLINE_INDEX_MAX of include/tsdf.h
 
 _lib = None
 
@@ -111,6 +112,8 @@ def load():
     L.tsdf_voxelize_indexed_hip.restype = ctypes.c_int
     L.tsdf_voxelize_indexed_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int,
                                             cam_p, ctypes.c_int, vp, vp, vp, vp, vp, lab_p]
+    L.tsdf_voxelize_indexed_host_hip.restype = ctypes.c_int
+    L.tsdf_voxelize_indexed_host_hip.argtypes = L.tsdf_voxelize_indexed_hip.argtypes
     L.tsdf_voxelize_indexed_aug_hip.restype = ctypes.c_int
     L.tsdf_voxelize_indexed_aug_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int,
                                                 cam_p, ctypes.c_int, vp, vp, vp, vp, vp, vp, lab_p]

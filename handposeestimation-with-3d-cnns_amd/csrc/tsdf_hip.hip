@@ -1252,6 +1252,8 @@ struct KArgs {
   int64_t depth_len;
   const int64_t *index;   // tsdf_voxelize_indexed_hip: batch position -> frame of the resident pack (else null)
   int64_t n_src;          // ... and the number of frames in that pack
+  int n_inline;           // tsdf_voxelize_indexed_host_hip: the index travels IN the kernel arguments (n <= kInlineIndex)
+  int64_t inline_index[TSDF_INLINE_INDEX_MAX];
   const float *gt;        // labels (optional)
   float *gt_nor, *gt_aug;
   int n_joints, clamp;
@@ -1283,7 +1285,11 @@ __device__ __forceinline__ void fetch_header(const KArgs &a, const int64_t *__re
                                              const int32_t *__restrict__ in_headers, int fr, FrameHdr &m) {
   int64_t src = fr;
   bool ok = true;
-  if (a.index) {
+  if (a.n_inline) {           // a small batch whose index came by value: no memory outside the kernel arguments is read
+    src = a.inline_index[fr];
+    ok = src >= 0 && src < a.n_src;
+    if (!ok) src = 0;
+  } else if (a.index) {
     src = a.index[fr];
     ok = src >= 0 && src < a.n_src;
     if (!ok) src = 0;
@@ -2377,6 +2383,7 @@ struct RunOpts {
   int32_t *pixmap = nullptr;
   const int64_t *index = nullptr;  // indexed entry
   int64_t n_src = 0;
+  const int64_t *h_index = nullptr;  // indexed entry, index in HOST memory, copied into the kernel arguments
 };
 
 int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
@@ -2424,6 +2431,11 @@ int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const
   a.depth_len = depth_len;
   a.index = o.index;
   a.n_src = o.n_src;
+  if (o.h_index) {
+    if (n > TSDF_INLINE_INDEX_MAX) return TSDF_ERR_INVALID_ARG;
+    a.n_inline = n;
+    memcpy(a.inline_index, o.h_index, sizeof(int64_t) * (size_t)n);
+  }
   if (o.labels) {
     a.gt = o.labels->d_gt;
     a.gt_nor = o.labels->d_out_gt_nor;
@@ -2574,6 +2586,20 @@ int tsdf_voxelize_indexed_hip(const float *d_depth, int64_t depth_len, const int
   RunOpts o;
   o.labels = labels;
   o.index = d_index;
+  o.n_src = n_pack;
+  return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
+             d_out_mid_p, d_out_status, o);
+}
+
+int tsdf_voxelize_indexed_host_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                                   const int32_t *d_headers, int64_t n_pack, const int64_t *h_index, int n, int R,
+                                   const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf, float *d_out_max_l,
+                                   float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels) {
+  if (n > 0 && (!d_out_tsdf || !d_out_max_l || !d_out_mid_p || !h_index)) return TSDF_ERR_INVALID_ARG;
+  if (n_pack < 0 || (n > 0 && n_pack == 0) || n > TSDF_INLINE_INDEX_MAX) return TSDF_ERR_INVALID_ARG;
+  RunOpts o;
+  o.labels = labels;
+  o.h_index = h_index;
   o.n_src = n_pack;
   return run(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, hip_stream, d_out_tsdf, d_out_max_l,
              d_out_mid_p, d_out_status, o);

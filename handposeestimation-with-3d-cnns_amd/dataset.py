@@ -801,6 +801,13 @@ class MSRA_Dataset(data.Dataset):
             self.take = (rp.frame if frame is None else frame).take   # dataset item -> frame of the resident packs
             self.rows = [self.h_idx_np[k] for k in range(ring)]
             assert self.kGroup == 16
+            # batches of at most INLINE_INDEX_MAX frames: the index goes to the GPU inside the kernel arguments
+            # (tsdf_voxelize_indexed_host_hip reads it during the call) — no page-locked slot, no event, and the launch
+            # does not start with a read over the link
+            self.by_value = xf_table is None and bs <= _lib.INLINE_INDEX_MAX
+            self.fn_host = self.L.tsdf_voxelize_indexed_host_hip
+            self.idx_buf = np.empty(bs, np.int64)
+            self.idx_ptr = self.idx_buf.ctypes.data
             self.xf_take = None
             if xf_table is not None:   # aug=True: one map per batch position, in page-locked memory the kernel reads
                 self.fn_aug = self.L.tsdf_voxelize_indexed_aug_hip
@@ -820,6 +827,18 @@ class MSRA_Dataset(data.Dataset):
             f = self._fast = MSRA_Dataset._Fast(self._rp, n, ring, self.device,
                                                 frame=self._frame2 if self.AUG else None, xf_table=self._xf_table)
         k = f.slot
+        if f.by_value:                        # (the epoch's short last batch, or another current device)
+            f.idx_buf[:n] = f.take(indices)
+            a = f.args[k]
+            with torch.cuda.device(f.device):
+                rc = f.fn_host(*f.head, f.idx_ptr, n, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
+            if rc != 0:
+                from . import _lib
+                _lib.check(rc, "tsdf_voxelize_indexed_host_hip")
+            f.slot = k + 1 if k + 1 < f.ring else 0
+            if n == f.bs:
+                return f.results[k]
+            return [PreBatched((f.tsdf[k, :n], f.gt[k, :n], f.max_l[k, :n], f.mid_p[k, :n]))]
         within = k & (f.kGroup - 1)
         if within == 0 and f.read_used[k >> 4]:
             f.read[k >> 4].synchronize()      # the launches that read this group's index words a ring ago are done
@@ -862,18 +881,14 @@ class MSRA_Dataset(data.Dataset):
             raise RuntimeError("MSRA_Dataset produces its items on the GPU: use it with num_workers=0 (the reference's "
                                "default, train.py:38), there is nothing for loader processes to do")
         f = self._fast
-        if f is not None and f.xf_take is None and len(indices) == f.bs and f.cur_dev() == f.dev_index:
+        if f is not None and f.by_value and len(indices) == f.bs and f.cur_dev() == f.dev_index:
             # the hot path of a training epoch, inlined (every microsecond here is 6 % of a batch of 16): a full batch of
-            # plain items on the current device — indices into the ring slot, one C call, the slot's prebuilt result
+            # plain items on the current device — item -> pack frame, one C call that takes the index by value, the
+            # ring slot's prebuilt result
             k = f.slot
-            if not (k & 15) and f.read_used[k >> 4]:
-                f.read[k >> 4].synchronize()
-            f.take(indices, out=f.rows[k])
+            f.take(indices, out=f.idx_buf)
             a = f.args[k]
-            rc = f.fn(*f.head, a[0], f.bs, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
-            if (k & 15) == 15:
-                f.read[k >> 4].record(torch.cuda.current_stream(f.device))
-                f.read_used[k >> 4] = True
+            rc = f.fn_host(*f.head, f.idx_ptr, f.bs, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
             if rc != 0:
                 from . import _lib
                 _lib.check(rc, "tsdf_voxelize_indexed_hip")

@@ -195,15 +195,20 @@ def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.
                      out_gt_nor: Optional[torch.Tensor] = None, out_gt: Optional[torch.Tensor] = None):
     """A batch drawn by index from a pack that lives on the GPU (``tsdf_voxelize_indexed_hip``): ``depth`` /
     ``offsets[N+1]`` / ``headers[N,6]`` (and ``gt[N,3J]``) describe the whole pack, uploaded once; frame i of the batch is
-    pack frame ``index[i]`` (int64[n], any order — a shuffled minibatch; device or pinned host memory).  Outputs are in
-    batch order.  Bit-identical to :func:`voxelize_labels` on the gathered frames.  Returns ``TsdfBatch`` without ``gt``,
+    pack frame ``index[i]`` (int64[n], any order — a shuffled minibatch; device or pinned host memory; or, for
+    n <= 32 without ``xforms``, an ordinary CPU tensor, which is read during the call and travels to the GPU inside the
+    kernel arguments: ``tsdf_voxelize_indexed_host_hip``).  Outputs are in batch order.  Bit-identical to :func:`voxelize_labels` on the gathered frames.  Returns ``TsdfBatch`` without ``gt``,
     else ``(TsdfBatch, gt_nor)`` or, with ``gt_copy=True``, ``(TsdfBatch, gt_nor, gt_of_the_batch)``.
     ``xforms`` float64[n,24] on the GPU (one map per batch position, as for :func:`voxelize_aug`) adds the fused 3-D
     augmentation: the labels are then mapped with it, ``gt_of_the_batch`` is ``T(joints)``.
     ``out`` / ``out_gt_nor`` / ``out_gt`` (the latter implies ``gt_copy``): preallocated outputs of exactly the batch's
     shapes — a loader's ring buffers; nothing is allocated then."""
     L = _lib.load()
-    _dev_check("index", index, torch.int64, depth.device if isinstance(depth, torch.Tensor) else None, host_ok=True)
+    by_value = isinstance(index, torch.Tensor) and not index.is_cuda and not index.is_pinned() and \
+        index.dtype is torch.int64 and index.dim() == 1 and index.is_contiguous() and \
+        index.numel() <= _lib.INLINE_INDEX_MAX and xforms is None
+    if not by_value:   # (a small index in ordinary host memory travels inside the kernel arguments instead)
+        _dev_check("index", index, torch.int64, depth.device if isinstance(depth, torch.Tensor) else None, host_ok=True)
     if index.dim() != 1:
         raise ValueError("index must have shape [n]")
     dev, n_pack, R = _check_inputs(L, depth, offsets, headers, res, layout)
@@ -238,7 +243,9 @@ def voxelize_indexed(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.
                     ctypes.byref(cam) if cam is not None else None, _lib.LAYOUTS[layout], _raw_stream(dev))
             tail = (out.tsdf.data_ptr(), out.max_l.data_ptr(), out.mid_p.data_ptr(), out.status.data_ptr(),
                     ctypes.byref(lab) if lab is not None else None)
-            if xforms is None:
+            if by_value:
+                rc = L.tsdf_voxelize_indexed_host_hip(*head, *tail)
+            elif xforms is None:
                 rc = L.tsdf_voxelize_indexed_hip(*head, *tail)
             else:
                 rc = L.tsdf_voxelize_indexed_aug_hip(*head, xforms.data_ptr(), *tail)

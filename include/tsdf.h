@@ -286,6 +286,18 @@ int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_
 
 /* ---- ABI v5 additions ---------------------------------------------------------------------------- */
 
+/* tsdf_voxelize_indexed_hip for SMALL batches whose index is in ordinary HOST memory: h_index[0..n), n <=
+ * TSDF_INLINE_INDEX_MAX, is read DURING the call and travels to the GPU inside the kernel arguments — no upload, no
+ * page-locked buffer whose lifetime the caller has to manage, and no read over the link on the launch's critical path (a
+ * kernel that fetches its 16 indices from page-locked host memory starts ~2 us later: at the reference's batch size, 16 —
+ * 3D_CNN/train.py:36 — that is a tenth of the launch).  What a DataLoader-driven training step calls once per batch.
+ * Everything else as tsdf_voxelize_indexed_hip. */
+#define TSDF_INLINE_INDEX_MAX 32
+int tsdf_voxelize_indexed_host_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets,
+                                   const int32_t *d_headers, int64_t n_pack, const int64_t *h_index, int n, int R,
+                                   const tsdf_cam *cam, int layout, void *hip_stream, float *d_out_tsdf, float *d_out_max_l,
+                                   float *d_out_mid_p, int32_t *d_out_status, const tsdf_labels *labels);
+
 /* tsdf_host_gather_frames with the LENGTH of the source buffer (src_len elements): a frame whose
  * [src_offsets[f], src_offsets[f+1]) does not lie inside [0, src_len) — a damaged pack file — makes the call return
  * TSDF_ERR_INVALID_ARG before anything is copied, instead of reading outside the mapping.  The v4 entry above trusts

@@ -1170,7 +1170,29 @@ def test_indexed_batches_from_a_resident_pack(pkg, synth):
     good = pkg.voxelize_indexed(td, to, th, torch.tensor([5, 9], device=d), tg)
     assert torch.equal(good[0].tsdf, got[0].tsdf[[0, 3]]) and torch.equal(good[1], got[1][[0, 3]])
     with pytest.raises(ValueError):
-        pkg.voxelize_indexed(td, to, th, torch.from_numpy(idx), tg)       # pageable index
+        pkg.voxelize_indexed(td, to, th, torch.from_numpy(idx), tg)       # a pageable index of 40: too long to go by value
+    # ABI v5: a small index in ordinary host memory goes to the GPU INSIDE the kernel arguments
+    # (tsdf_voxelize_indexed_host_hip): same result as the device index, bad entries included, and the host buffer may be
+    # overwritten as soon as the call has returned
+    for n_small in (1, 16, 32):
+        small = rng.integers(0, N, n_small).astype(np.int64)
+        if n_small == 16:
+            small[[3, 7]] = [-5, N + 1]
+        want = pkg.voxelize_indexed(td, to, th, torch.from_numpy(small).to(d), tg, gt_copy=True)
+        host = torch.from_numpy(small.copy())
+        got = pkg.voxelize_indexed(td, to, th, host, tg, gt_copy=True)
+        host.fill_(0)                                                       # (the call has read it already)
+        torch.cuda.synchronize()
+        for a, b in zip(want[0], got[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(want[1], got[1])
+        if n_small != 16:       # (a bad index copies no labels: those rows are whatever the allocation held)
+            assert torch.equal(want[2], got[2])
+    L = pkg._lib.load()
+    out33 = pkg.voxelize_indexed(td, to, th, torch.zeros(33, dtype=torch.int64, device=d))
+    assert L.tsdf_voxelize_indexed_host_hip(td.data_ptr(), td.numel(), to.data_ptr(), th.data_ptr(), N,
+                                            np.zeros(33, np.int64).ctypes.data, 33, 32, None, 0, None, out33.tsdf.data_ptr(),
+                                            out33.max_l.data_ptr(), out33.mid_p.data_ptr(), out33.status.data_ptr(), None) == -1
 
 
 def test_resident_loader(pkg, synth):
