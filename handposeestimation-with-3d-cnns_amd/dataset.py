@@ -501,7 +501,12 @@ class ResidentLoader:
         rp = ResidentPacks(self.ds, self.device)
         self._dev = (rp.depth, rp.offsets, rp.headers, rp.gt)
         self._g = rp.frame
-        self._idx = [(torch.empty(self.bs, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        from . import _lib
+        # (batches of up to 32 frames hand their index over by value — tsdf_voxelize_indexed_host_hip —, which an ordinary
+        # CPU tensor selects in voxelize_indexed; larger ones, and augmented ones, are read from page-locked memory)
+        pin = self.bs > _lib.INLINE_INDEX_MAX or self.augment
+        self._idx = [(torch.empty(self.bs, dtype=torch.int64).pin_memory() if pin else torch.empty(self.bs, dtype=torch.int64),
+                      torch.cuda.Event()) for _ in range(2)]
         self._used = [False, False]
         self._mid = None
         if self.augment:   # the centres the maps turn about: every frame's own grid centre, one AABB launch over the pack
