@@ -763,9 +763,11 @@ class MSRA_Dataset(data.Dataset):
 
     # ---- the pre-batched path: one C call per batch, nothing allocated, nothing sliced ----
     class _Fast:
-        """Ring state for batches of (at most) ``bs`` frames: page-locked index slots the kernel reads over the link,
-        output slots, one prebuilt result per slot, the C call's constant arguments, and one event per ``kGroup`` slots
-        that tells when their index words have been read (a slot's words are rewritten ``ring`` batches later)."""
+        """Ring state for batches of (at most) ``bs`` frames: output slots, one prebuilt result per slot and the C call's
+        constant arguments.  Batches of up to 32 plain frames hand their index to the GPU by value (``by_value``:
+        ``tsdf_voxelize_indexed_host_hip``); larger ones, and ``aug=True`` datasets, write it into page-locked index slots
+        the kernel reads over the link, with one event per ``kGroup`` slots that tells when a group's words have been read
+        (a slot's words are rewritten ``ring`` batches later)."""
 
         kGroup = 16
 
