@@ -1278,6 +1278,16 @@ def test_msra_dataset_prebatched_under_the_reference_loader_call(pkg, synth):
             assert torch.equal(t1, t2) and torch.equal(g1, g2) and torch.equal(l1, l2) and torch.equal(m1, m2)
             nb += 1
         assert nb == 13
+    assert fast._fast.by_value                       # batches of 16: the index travels in the kernel arguments
+    # batches of 40 (> 32): the index sits in page-locked ring slots guarded by events; 6 batches per epoch x 4 epochs
+    # turn the ring of 16 once and a half
+    big = pkg.MSRA_Dataset.from_raw(raw, device=d, ring=16)
+    for epoch in range(4):
+        a = DL(big, batch_size=40, shuffle=True, generator=torch.Generator().manual_seed(10 + epoch))
+        b = DL(slow, batch_size=40, shuffle=True, generator=torch.Generator().manual_seed(10 + epoch))
+        for (t1, g1, l1, m1), (t2, g2, l2, m2) in zip(a, b):
+            assert torch.equal(t1, t2) and torch.equal(g1, g2) and torch.equal(l1, l2) and torch.equal(m1, m2)
+    assert not big._fast.by_value and big._fast.ring == 16
     ref = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=32, n_threads=8)
     one = fast[77]
     for _ in DL(fast, batch_size=16):   # a whole epoch later the item is still what it was
