@@ -909,6 +909,9 @@ def main():
                 "ms_per_step_events": [round(float(v) / args.steps, 4) for v in timing[:, 1]],
                 "ms_per_step_host_wall": [round(float(v) / args.steps * 1e3, 4) for v in timing[:, 0]],
                 "frames_per_s_events": [round(FRAMES_PER_GPU * n_launch / (float(v) * 1e-3)) for v in timing[:, 1]],
+                # every rank's own roofline fraction: its algorithmic bytes per second over the 8 TB/s of ITS GPU
+                "frac_of_hbm_peak_events": [round(abytes * n_launch / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                            for v in timing[:, 1]],
                 "what": "every rank's own timed region: HIP events on its launch stream, and host wall between the two barriers",
             },
             "roofline": {

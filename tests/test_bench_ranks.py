@@ -125,7 +125,7 @@ def test_bench_multi_rank_path_runs_under_torchrun_with_gloo(tmp_path, world):
     total = world * 1024 * 16 * 3
     assert abs(j["value"] - total / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
     pr = j["per_rank"]
-    for key in ("ms_per_step_events", "ms_per_step_host_wall", "frames_per_s_events"):
+    for key in ("ms_per_step_events", "ms_per_step_host_wall", "frames_per_s_events", "frac_of_hbm_peak_events"):
         assert len(pr[key]) == world and all(v > 0 for v in pr[key])
     assert max(pr["ms_per_step_host_wall"]) == pytest.approx(j["ms_per_step"], rel=1e-3)
     aff = pr["affinity"]
