@@ -496,6 +496,14 @@ def one_frame_report(pkg, synth, dev):
         t0 = time.perf_counter()
         pkg.cal_tsdf_cuda(s)
         ts.append(time.perf_counter() - t0)
+    pc2 = np.array([[-60.0, -70.0, -480.0], [70.0, 60.0, -380.0]], np.float32)   # the loop entry takes its grid from a cloud
+    for _ in range(5):
+        pkg.tsdf_f({"header": h, "depth": d}, pc2)
+    tf = []
+    for _ in range(60):
+        t0 = time.perf_counter()
+        pkg.tsdf_f({"header": h, "depth": d}, pc2)
+        tf.append(time.perf_counter() - t0)
     td = torch.from_numpy(d).to(dev)
     to = torch.tensor([0, d.size], dtype=torch.int64, device=dev)
     th = torch.from_numpy(h[None]).to(dev)
@@ -519,8 +527,12 @@ def one_frame_report(pkg, synth, dev):
     return {
         "frame": f"one MSRA-like crop, bbox {int(h[4] - h[2])}x{int(h[5] - h[3])}, -> 32^3",
         "cal_tsdf_cuda_shim_s": round(float(np.median(ts)), 6),
-        "cal_tsdf_cuda_shim_what": "handposeestimation-with-3d-cnns_amd.tsdf_numba.cal_tsdf_cuda(s): pageable H2D of the crop + "
-                                   "header, ONE launch, status check, 393 KB volume + max_l + mid_p back to numpy (host wall, median of 60)",
+        "cal_tsdf_cuda_shim_what": "handposeestimation-with-3d-cnns_amd.tsdf_numba.cal_tsdf_cuda(s): offsets + header + crop up as ONE "
+                                   "page-locked block, ONE launch, volume + max_l + mid_p + status back as one block, one "
+                                   "synchronisation, numpy copies out (host wall, median of 60; the reference: 4 copies, 2 launches)",
+        "tsdf_f_shim_s": round(float(np.median(tf)), 6),
+        "tsdf_f_shim_what": "handposeestimation-with-3d-cnns_amd.tsdf_for.tsdf_f(data, point_cloud): the CPU-loop entry's signature "
+                            "(pre/tsdf_for.py:6-20; float64 [c,x,y,z] result) served by the GPU the same way",
         "voxelize_resident_s": round(float(np.median(singles)), 7),
         "voxelize_resident_what": "the same frame already on the GPU, one launch, result left there (HIP events, median of 60)",
         "oracle_one_core_s": round(float(np.median(tc)), 6),

@@ -14,7 +14,6 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .voxelize import voxelize_grid
 
 fFocal_msra = 241.42  # pre/tsdf_for.py:3
 
@@ -36,19 +35,35 @@ def _device():
 
 
 def tsdf_cal(data, vox_ori, voxel_len, truncation, voxel_res: int = 32):
-    """pre/tsdf_for.py:44-122 on the GPU -> float64[3,R,R,R] in [c,x,y,z]."""
+    """pre/tsdf_for.py:44-122 on the GPU -> float64[3,R,R,R] in [c,x,y,z].  One page-locked block up (offsets, header,
+    grid placement, depth), one back (the volume): tsdf_numba._Bufs."""
+    from . import _lib
+    from .tsdf_numba import _bufs
     header = np.ascontiguousarray(data["header"], dtype=np.int32).reshape(6)
     depth = np.ascontiguousarray(data["depth"], dtype=np.float32).reshape(-1)
     dev = _device()
-    grid = np.zeros((1, 8), np.float32)
-    grid[0, :3] = np.asarray(vox_ori, dtype=np.float32)
-    grid[0, 3] = np.float32(voxel_len)
-    grid[0, 4] = np.float32(truncation)
-    tsdf, _ = voxelize_grid(torch.from_numpy(depth).to(dev),
-                            torch.tensor([0, depth.size], dtype=torch.int64, device=dev),
-                            torch.from_numpy(header[None]).to(dev), torch.from_numpy(grid).to(dev),
-                            res=voxel_res, layout="cxyz")
-    return tsdf[0].cpu().numpy().astype(np.float64)
+    L = _lib.load()
+    if not L.tsdf_resolution_supported(int(voxel_res)):
+        raise ValueError(f"unsupported grid resolution {voxel_res} (multiple of 4 in 4..128)")
+    b = _bufs(dev, depth.size, int(voxel_res))
+    npx = depth.size
+    b.h_off[0], b.h_off[1] = 0, npx
+    b.h_hdr[:] = header
+    b.h_grid[:] = 0.0
+    b.h_grid[:3] = np.asarray(vox_ori, dtype=np.float32)
+    b.h_grid[3] = np.float32(voxel_len)
+    b.h_grid[4] = np.float32(truncation)
+    b.h_depth[:npx] = depth
+    nin = b.IN_HEAD + 4 * npx
+    stream = torch.cuda.current_stream(dev)
+    b.d_in[:nin].copy_(b.h_in[:nin], non_blocking=True)
+    rc = L.tsdf_voxelize_grid_hip(b.p_depth, npx, b.p_off, b.p_hdr, 1, int(voxel_res), None, _lib.TSDF_LAYOUT_CXYZ,
+                                  stream.cuda_stream, b.p_grid, b.p_tsdf, b.p_status)
+    _lib.check(rc, "tsdf_voxelize_grid_hip")
+    b.h_out.copy_(b.d_out, non_blocking=True)
+    stream.synchronize()
+    R = int(voxel_res)
+    return b.h_out_np[:b.nvol].reshape(3, R, R, R).astype(np.float64)
 
 
 def tsdf_f(data, point_cloud):
