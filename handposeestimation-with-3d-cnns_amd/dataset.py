@@ -243,7 +243,8 @@ def plan_batches(n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle
              EVERY RANK — what a training loop that steps a gradient collective once per batch needs.  A rank that is
              one frame short of another batch repeats its first frame in a final one-frame batch (as
              ``torch.utils.data.DistributedSampler`` pads); with ``drop_last`` every rank keeps
-             ``min(shard) // batch_size`` full batches.
+             ``min(shard) // batch_size`` full batches.  (Assumes n >= world: a rank without a single frame has nothing
+             to repeat and yields no batch.)
              ``"pixels"``: cut points balance ``weights`` (pixels per frame; MSRA boxes vary ~3x in area): equal WORK per
              rank, for voxelization / export jobs that never synchronise per batch.  Frame and batch counts then differ
              between ranks (8 ranks over MSRA-like subjects: 7 to 15 batches of 1024).
