@@ -221,6 +221,13 @@ __device__ __forceinline__ double div_by_focal(double d, const CamK &k) {
 //                 neither operand nor the quotient comes near the ends of the exponent range, so the result is the
 //                 same bit for bit; the caller proves 2^-600 < |vz| < 2^600 for a lane's whole column of voxels and
 //                 2^-100 < F < 2^100 before choosing this form (phase2_aug), anything else takes the division.
+// (TSDF_RCP_ONE_STEP=1, a measurement build only: v_rcp_f64 is good to 2^-24.4 on gfx950 (tools/probes/rcp64_probe.hip), so
+// ONE Newton step leaves 2^-48.7 and the corrected quotient is off by ~2^-97 before its final rounding — the IEEE
+// quotient on every one of 4.2 M probed divisors, but a quotient of two float64 can sit within 2^-107 of a rounding
+// boundary, so only the second step makes the result provably the division's.  It stays.)
+#ifndef TSDF_RCP_ONE_STEP
+#define TSDF_RCP_ONE_STEP 0
+#endif
 template <bool FAST>
 __device__ __forceinline__ double neg_focal_over(double vz, const CamK &k) {
   if constexpr (!FAST) {
@@ -229,7 +236,9 @@ __device__ __forceinline__ double neg_focal_over(double vz, const CamK &k) {
     const double n = -k.focal;
     double r = __builtin_amdgcn_rcp(vz);
     r = __builtin_fma(r, __builtin_fma(-vz, r, 1.0), r);
+#if !TSDF_RCP_ONE_STEP
     r = __builtin_fma(r, __builtin_fma(-vz, r, 1.0), r);
+#endif
     const double q0 = n * r;
     return __builtin_fma(__builtin_fma(-vz, q0, n), r, q0);
   }
