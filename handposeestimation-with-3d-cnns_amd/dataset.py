@@ -899,7 +899,7 @@ class MSRA_Dataset(data.Dataset):
             rc = f.fn_host(*f.head, f.idx_ptr, f.bs, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
             if rc != 0:
                 from . import _lib
-                _lib.check(rc, "tsdf_voxelize_indexed_hip")
+                _lib.check(rc, "tsdf_voxelize_indexed_host_hip")
             f.slot = k + 1 if k + 1 < f.ring else 0
             self._last = indices[-1]
             return f.results[k]
