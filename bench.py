@@ -285,7 +285,8 @@ class NodeBarrier:
         return True
 
     def __call__(self):
-        self._wait()
+        if not self._wait(600.0):   # a rank that died: fail instead of spinning for ever
+            raise RuntimeError(f"rank {self.rank}: node barrier {self.n} not reached by every rank within 600 s")
 
 
 # ---- the device under test, or its host stand-in ------------------------------------------------------------------
