@@ -73,3 +73,38 @@ def synth_batch(n: int, kind: str = "full", seed0: int = 0):
         offsets[i + 1] = offsets[i] + d.size
     depth = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.float32)
     return depth, offsets, headers
+
+
+def synth_msra_tree(root: str, n_sub: int = 4, n_ges: int = 5, n_frames: int = 2, seed: int = 0,
+                    kind: str = "crop") -> int:
+    """A small MSRA-shaped tree under ``root`` — ``<root>/P<s>/<g>/{joint.txt, 000000_depth.bin, ...}``
+    (pre/read_MSRA.py:46-50,79,99) — made of seeded synthetic frames and labels, byte-identical wherever it is
+    generated (the build container writes the reference-run fixtures from it, the tests regenerate it on the GPU box).
+    Gesture directories are named ``1..n_ges`` (sorted as strings, like the reference's ``sorted(os.listdir())``);
+    labels are written with 6 decimals, joints scattered about the frame's own hand (z = -depth).  Returns the frame
+    count."""
+    import os
+
+    rng = np.random.default_rng(977 + int(seed))
+    k = 0
+    for s in range(n_sub):
+        for g in range(n_ges):
+            gdir = os.path.join(root, "P%d" % s, "%d" % (g + 1))
+            os.makedirs(gdir, exist_ok=True)
+            rows = []
+            for i in range(n_frames):
+                h, d = synth_frame(5000 + 100 * int(seed) + k, kind)
+                with open(os.path.join(gdir, "%06d_depth.bin" % i), "wb") as f:
+                    h.tofile(f)
+                    d.tofile(f)
+                valid = d[d != 0]
+                zc = -float(valid.mean()) if valid.size else -400.0
+                j = rng.normal(0.0, 45.0, (21, 3))
+                j[:, 2] += zc
+                rows.append(j.reshape(63))
+                k += 1
+            with open(os.path.join(gdir, "joint.txt"), "w") as f:
+                f.write("%d\n" % n_frames)
+                for row in rows:
+                    f.write(" ".join("%.6f" % v for v in row) + "\n")
+    return k

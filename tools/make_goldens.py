@@ -25,6 +25,12 @@ What each fixture pins:
   joint_nor_ref  pre/joint_nor.py::normalize (:8-18) RUN on [n,21,3] float32 labels (the one shape it does not raise
           on: for the [n,63] arrays its callers hold, `joint_nor[i] = ...` cannot broadcast (21,3) into (63,)) with the
           goldens' own max_l / mid_p plus seeded extra frames: pins the label formula of SURVEY.md 8(f)#4.
+  io_ref  pre/read_MSRA.py::read_bin / read_joint (:143-164) RUN on tiny .bin / joint.txt files written here with plain
+          numpy / text: the file bytes and exactly what the reference returned (dtype, shape, values).  Pins row a1.
+  dataset_ref  3D_CNN/dataset.py::MSRA_Dataset (:16-117) RUN — train=True and train=False — on a 4-subject x 5-gesture
+          x 2-frame synthetic MSRA tree (synth.synth_msra_tree, regenerated from its seed by the tests) exported in the
+          reference's on-disk schema with the ORACLE as the voxelizer (no GPU here): length, item order, dtypes, shapes,
+          gt / max_l / mid_p of every item, the volumes of a few.  Pins row f1 to the class instead of to a reading of it.
   aabb_*  the numba-typing AABB (pre/tsdf_numba.py:84-96,140-141) from
           oracle/tsdf_oracle_np.py — a restatement, not a run (min_max_kernel cannot
           be executed here: no usable numba, no params.py).
@@ -168,10 +174,133 @@ def run_reference_joint_nor(outdir, golden_scales):
           f"({int((want < 0).sum())} coordinates < 0, {int((want > 1).sum())} > 1)")
 
 
-def main():
+def run_reference_io(outdir):
+    """io_ref.npz: the reference's own read_bin / read_joint (pre/read_MSRA.py:143-164) on files written here.
+    Stored: every file's bytes (uint8) and what the reference returned for it.  read_joint returns a 1-D array for a
+    one-frame gesture (np.loadtxt squeezes); the fixture keeps that shape — packing.read_joint documents its [1,63]."""
+    import tempfile
+
+    sys.path.insert(0, REF_PRE)
+    import read_MSRA as ref_io  # noqa: E402  (the reference; pulls scipy.io, process, joint_pca — all importable)
+
+    rng = np.random.default_rng(31337)
+    bins = {}
+    # odd width (rows not 16-byte aligned), zeros and sub-threshold values inside
+    d = rng.uniform(250, 600, 17 * 5).astype(np.float32)
+    d[rng.random(d.size) < 0.3] = 0.0
+    d[3] = 0.5
+    bins["odd_17x5"] = (np.array([320, 240, 100, 60, 117, 65], np.int32), d)
+    # one pixel
+    bins["one_pixel"] = (np.array([320, 240, 7, 9, 8, 10], np.int32), np.array([431.25], np.float32))
+    # a whole 320x240 frame (the synthetic generator's)
+    bins["full_frame"] = synth.synth_frame(3, "full")
+    # payload bytes a text-mode read could mangle (the reference opens the file with 'r', :157): CR, LF, CR LF, ^Z, 0xFF
+    raw = np.frombuffer(bytes([0x0d, 0x0a, 0x0d, 0x0a, 0x1a, 0x00, 0x0a, 0x43, 0xff, 0xfe, 0x0d, 0x44, 0x0a, 0x0a, 0x0a,
+                               0x44] * 3), dtype=np.float32).copy()
+    bins["text_mode_bytes"] = (np.array([320, 240, 0, 0, 4, 3], np.int32), raw)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (h, dep) in bins.items():
+            fn = os.path.join(tmp, name + ".bin")
+            with open(fn, "wb") as f:
+                f.write(np.asarray(h, np.int32).tobytes())
+                f.write(np.asarray(dep, np.float32).tobytes())
+            rh, rd = ref_io.read_bin(fn)
+            assert rh.dtype == np.int32 and rd.dtype == np.float32
+            out["bin_%s_bytes" % name] = np.fromfile(fn, dtype=np.uint8)
+            out["bin_%s_header" % name] = rh
+            out["bin_%s_depth" % name] = rd
+        for n in (1, 3):
+            gdir = os.path.join(tmp, "ges%d" % n)
+            os.makedirs(gdir)
+            rows = rng.normal(0, 80, (n, 63))
+            rows[:, 2::3] -= 400.0
+            with open(os.path.join(gdir, "joint.txt"), "w") as f:
+                f.write("%d\n" % n)
+                for r in rows:   # MSRA's own files separate with single spaces; mixed precision on purpose
+                    f.write(" ".join(("%.6f" if k % 2 else "%.3f") % v for k, v in enumerate(r)) + "\n")
+            cnt, gt = ref_io.read_joint(gdir)
+            assert gt.dtype == np.float32
+            out["joint%d_bytes" % n] = np.fromfile(os.path.join(gdir, "joint.txt"), dtype=np.uint8)
+            out["joint%d_count" % n] = np.int64(cnt)
+            out["joint%d_gt" % n] = gt
+    out["bin_names"] = np.array(sorted(bins))
+    np.savez_compressed(os.path.join(outdir, "io_ref.npz"), **out)
+    print("io_ref: %d .bin files + 2 joint.txt through pre/read_MSRA.py::read_bin / read_joint "
+          "(joint.txt with one frame -> shape %s)" % (len(bins), out["joint1_gt"].shape,))
+
+
+DATASET_TREE = dict(n_sub=4, n_ges=5, n_frames=2, seed=0, kind="crop")
+
+
+def run_reference_dataset(outdir):
+    """dataset_ref.npz: the reference's own MSRA_Dataset (3D_CNN/dataset.py:16-117) over an export of a synthetic tree.
+    The export is this project's export.preprocess_tree with the ORACLE as the voxelizer and gt_3d=True (the one label
+    form the reference reader does not crash on, App. B#11); the class is run in a child interpreter (it sets
+    CUDA_VISIBLE_DEVICES at import, :12-13)."""
+    import hashlib
+    import subprocess
+    import tempfile
+
+    import oracle
+    pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
+
+    def vox(pk, res, layout, device):
+        r = oracle.voxelize(pk.depth, pk.offsets, pk.headers, R=res, layout=0 if layout == "czyx" else 1)
+        return r["tsdf"], r["max_l"], r["mid_p"], r["status"]
+
+    with tempfile.TemporaryDirectory() as tmp:
+        db, res = os.path.join(tmp, "db"), os.path.join(tmp, "result")
+        total = synth.synth_msra_tree(db, **DATASET_TREE)
+        pkg.export.preprocess_tree(db, res, gt_3d=True, point_clouds=False, voxelize_fn=vox)
+        child = r"""
+import sys, numpy as np
+sys.path.insert(0, "/root/reference/3D_CNN")
+import dataset as ref_ds
+out = {}
+for name, train in (("train", True), ("test", False)):
+    ds = ref_ds.MSRA_Dataset(sys.argv[1], None, train=train)
+    n = len(ds)
+    items = [ds[i] for i in range(n)]
+    assert all(len(it) == 4 for it in items)
+    out[name + "_len"] = np.int64(n)
+    out[name + "_tsdf"] = np.stack([it[0] for it in items])
+    out[name + "_gt"] = np.stack([it[1] for it in items])
+    out[name + "_max_l"] = np.stack([it[2] for it in items])
+    out[name + "_mid_p"] = np.stack([it[3] for it in items])
+    out[name + "_item_types"] = np.array([type(x).__name__ + ":" + str(np.asarray(x).dtype) + ":" + str(np.asarray(x).shape) for x in items[0]])
+np.savez(sys.argv[2], **out)
+"""
+        raw = os.path.join(tmp, "ref_items.npz")
+        subprocess.run([sys.executable, "-c", child, res, raw], check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+        z = np.load(raw)
+        out = {"tree": np.array(["%s=%s" % kv for kv in sorted(DATASET_TREE.items())]), "total_frames": np.int64(total)}
+        keep = {"train": [0, 1, 9, 10, 19, 29], "test": [0, 9]}   # volumes kept whole; every item keeps a digest
+        for name in ("train", "test"):
+            n = int(z[name + "_len"])
+            tsdf = z[name + "_tsdf"]
+            assert tsdf.dtype == np.float32 and tsdf.shape == (n, 3, 32, 32, 32)
+            for k in ("gt", "max_l", "mid_p", "item_types", "len"):
+                out["%s_%s" % (name, k)] = z["%s_%s" % (name, k)]
+            out[name + "_tsdf_sha256"] = np.array([hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for v in tsdf])
+            idx = np.array([i for i in keep[name] if i < n], np.int64)
+            out[name + "_kept"] = idx
+            out[name + "_tsdf_kept"] = tsdf[idx]
+        np.savez_compressed(os.path.join(outdir, "dataset_ref.npz"), **out)
+        print("dataset_ref: 3D_CNN/dataset.py::MSRA_Dataset over a %d-frame export: len(train)=%d len(test)=%d, item %s"
+              % (total, int(z["train_len"]), int(z["test_len"]), list(z["train_item_types"])))
+
+
+def main(only=None):
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    if only:   # regenerate some of the reference-run fixtures without touching the volume goldens
+        for name in only:
+            {"aug": run_reference_aug, "io": run_reference_io, "dataset": run_reference_dataset}[name](outdir)
+        return
     run_reference_aug(outdir)
+    run_reference_io(outdir)
+    run_reference_dataset(outdir)
     frames = []
     for s in (0, 1, 2):
         h, d = synth.synth_frame(s, "full")
@@ -202,6 +331,7 @@ def main():
 if __name__ == "__main__":
     import argparse
 
-    argparse.ArgumentParser(description="Regenerate tests/golden/*.npz by running the reference's own code "
-                                        "(needs /root/reference; no options).").parse_args()
-    main()
+    ap = argparse.ArgumentParser(description="Regenerate tests/golden/*.npz by running the reference's own code "
+                                             "(needs /root/reference).")
+    ap.add_argument("--only", default="", help="comma list of aug,io,dataset: just these fixtures")
+    main([x for x in ap.parse_args().only.split(",") if x])

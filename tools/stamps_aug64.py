@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Where a 64^3 launch's time goes, per frame and per CU, from the in-kernel stamps (diagnostic library only:
+make -C handposeestimation-with-3d-cnns_amd/csrc stamps -> build/libtsdf_hip_stamps.so).  Run on the GPU box:
+
+    python tools/stamps_aug64.py                 (augmented entry, 1024 full frames -> 64^3: BASELINE configs[4])
+    STAMPS_AUG=0 python tools/stamps_aug64.py    (the plain 64^3 kernel)
+    PROF_KIND=crop / PROF_R=48 / PROF_FRAMES=2048 as in the other stamps tools
+
+The one-group-per-CU instantiations (R >= 48) run a frame's steps strictly one after the other on a CU, so the table
+is a partition of the CU's time:  fetch (queue ticket + header + barrier) | rows (wave 0's row stream) | extremes |
+extents barrier (= the slowest wave's rows) | glue | stage issue | tables | stage wait | barrier | voxel pass.
+Stamps are taken by lane 0 of wave 0 (s_memrealtime, 10 ns ticks) and never cleared, so entries older than the last
+launch's first start are ignored.
+"""
+import ctypes, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+aug = importlib.import_module("handposeestimation-with-3d-cnns_amd.augment")
+L = ctypes.CDLL(os.environ.get("STAMPS_LIB") or os.path.join(ROOT, "build", "libtsdf_hip_stamps.so"))
+vp = ctypes.c_void_p
+L.tsdf_voxelize_hip.restype = ctypes.c_int
+L.tsdf_voxelize_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, vp]
+L.tsdf_voxelize_aug_hip.restype = ctypes.c_int
+L.tsdf_voxelize_aug_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
+                                    vp, vp, vp]
+L.tsdf_debug_read_stamps.restype = ctypes.c_int
+L.tsdf_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dev = torch.device("cuda:0")
+N = int(os.environ.get("PROF_FRAMES", "1024"))
+R = int(os.environ.get("PROF_R", "64"))
+kind = os.environ.get("PROF_KIND", "full")
+AUG = os.environ.get("STAMPS_AUG", "1") == "1"
+depth, off, hdr = synth.synth_batch(N, kind, seed0=0)
+td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
+t = torch.empty((N, 3, R, R, R), dtype=torch.float32, device=dev)
+ml = torch.empty(N, dtype=torch.float32, device=dev); mp = torch.empty((N, 3), dtype=torch.float32, device=dev)
+st = torch.empty(N, dtype=torch.int32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def plain():
+    assert L.tsdf_voxelize_hip(td.data_ptr(), td.numel(), to.data_ptr(), th.data_ptr(), N, R, None, 0, stream,
+                               t.data_ptr(), ml.data_ptr(), mp.data_ptr(), st.data_ptr()) == 0
+
+
+plain()
+torch.cuda.synchronize()
+txf = torch.from_numpy(aug.random_affines(mp.cpu().numpy(), rng=np.random.RandomState(2026))[0]).to(dev)
+
+
+def launch():
+    if not AUG:
+        return plain()
+    assert L.tsdf_voxelize_aug_hip(td.data_ptr(), td.numel(), to.data_ptr(), th.data_ptr(), N, R, None, 0, stream,
+                                   txf.data_ptr(), t.data_ptr(), ml.data_ptr(), mp.data_ptr(), st.data_ptr()) == 0
+
+
+SL, FR, BL = 16, 8, 512
+names = ["fetch", "rows(w0)", "extremes", "partials", "ext.barrier+glue", "stage issue", "tables", "stage wait", "barrier",
+         "voxel pass"]
+for rep in range(int(os.environ.get("STAMPS_REPS", "2"))):
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); launch(); e.record(); torch.cuda.synchronize()
+    buf = np.zeros(BL * FR * SL, np.uint64)
+    assert L.tsdf_debug_read_stamps(buf.ctypes.data, buf.size) == buf.size
+    s = buf.reshape(BL, FR, SL).astype(np.int64)[:256]
+    first = s[:, 0, 0]
+    t0 = first[first > first.max() - 100000].min()           # this launch's earliest frame start
+    live = s[:, :, 0] >= t0                                     # [CU][frame ordinal]
+    cnt = live.sum(axis=1)
+    end = np.where(live, s[:, :, 9], 0).max(axis=1) - t0
+    print(f"== rep {rep}: {N} {kind} frames -> {R}^3, {'augmented' if AUG else 'plain'}; launch {a.elapsed_time(e) * 1e3:.1f} us by events "
+          f"(the stamps build is a few % slower than the product)")
+    print("   frames per CU: " + ", ".join(f"{k}:{int((cnt == k).sum())}" for k in range(cnt.max() + 1)))
+    q = np.percentile(end / 100.0, [0, 10, 50, 90, 100])
+    print("   CU end (us after the first start) min/p10/p50/p90/max: " + " ".join(f"{x:7.1f}" for x in q))
+    print(f"   CU idle at the end (max end - own end): mean {np.mean(end.max() - end) / 100:.1f} us = "
+          f"{100 * np.mean(end.max() - end) / end.max():.1f} % of the launch")
+    tot = np.zeros(10)
+    nfr = 0
+    for it in range(min(FR, cnt.max())):
+        lv = live[:, it]
+        if not lv.any():
+            continue
+        seg = np.zeros((int(lv.sum()), 10))
+        prev_end = s[lv, it - 1, 9] if it else np.full(int(lv.sum()), t0)
+        seg[:, 0] = s[lv, it, 0] - prev_end                   # close barrier + ticket + header + barrier
+        if it == 0:
+            seg[:, 0] = s[lv, it, 0] - t0
+        for k in range(1, 10):
+            seg[:, k] = s[lv, it, k] - s[lv, it, k - 1]
+        seg /= 100.0
+        tot += seg.sum(axis=0)
+        nfr += seg.shape[0]
+        dur = seg.sum(axis=1)
+        print(f"   frame #{it} (n={seg.shape[0]:3d}): total median {np.median(dur):6.1f} us (p90 {np.percentile(dur, 90):6.1f});  "
+              + "  ".join(f"{names[k]} {np.median(seg[:, k]):5.1f}" for k in range(10)))
+    share = tot / tot.sum() * 100
+    print("   share of all CU time: " + "  ".join(f"{names[k]} {share[k]:4.1f} %" for k in range(10)))
+    pro = share[:9].sum()
+    print(f"   => prologue (everything but the voxel pass) {pro:.1f} %, voxel pass {share[9]:.1f} %; "
+          f"mean per frame: prologue {tot[:9].sum() / nfr:.1f} us, voxel pass {tot[9] / nfr:.1f} us")
