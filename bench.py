@@ -69,16 +69,6 @@ def algorithmic_bytes(offsets: np.ndarray, n: int, R: int) -> int:
     return 4 * n_px + n * (24 + 8 + 12 * R ** 3 + 16)
 
 
-def host_threads() -> int:
-    """Threads for the CPU baseline: the cores this process may use, capped at the 1-GPU box's CPU
-    share (16) so that the baseline does not oversubscribe a shared host."""
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    return max(1, min(avail, 16))
-
-
 # ---- CPU affinity: each rank on the cores next to its GPU --------------------------------------------------------
 def _parse_cpulist(txt: str):
     cpus = set()
@@ -207,15 +197,36 @@ def pin_rank(local_rank: int, local_world: int, n_devices_hint: "int | None", re
     return rep
 
 
-def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
-    """Time the oracle on host cores over the same frames: ~4 s on one thread plus ~1.5 s wall on all
-    threads (16 on the GPU box: about 28 s of CPU work in total).  Whole passes over the 1024-frame batch are repeated until
-    the leg's budget is used, so the sample is always a multiple of the bench workload."""
+def allowed_cpus():
+    """The CPUs this process was allowed when it started (captured at import, before any rank pins itself next to its GPU)."""
+    return set(_ALLOWED_AT_START) if _ALLOWED_AT_START else set(range(os.cpu_count() or 1))
+
+
+try:
+    _ALLOWED_AT_START = frozenset(os.sched_getaffinity(0))
+except AttributeError:   # pragma: no cover
+    _ALLOWED_AT_START = frozenset()
+
+
+def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5, all_s=2.5):
+    """Time the oracle on host cores over the same frames, as BASELINE.md section 4 / SURVEY.md 8(d) ask: ONE thread and ALL
+    the cores the process is allowed (the count printed), plus the 16-thread figure earlier rounds reported (a one-GPU
+    box's nominal CPU share).  Whole passes over the 1024-frame batch are repeated until a leg's budget is used, so the
+    sample is always a multiple of the bench workload; about 4 + 1.5 x 16 + 2.5 x allowed seconds of CPU work.  The rank
+    pinned itself to its GPU's NUMA node at start-up: for this measurement the mask the process STARTED with is put back
+    (OpenMP workers inherit the mask of the thread that creates them) and the pinned one restored afterwards."""
     import oracle  # test infrastructure; used here only as the reported CPU baseline
 
     oracle.lib()  # build/load outside the timed region
     n = FRAMES_PER_GPU
-    threads = host_threads()
+    allowed = allowed_cpus()
+    pinned = None
+    try:
+        pinned = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, allowed)
+    except (AttributeError, OSError):
+        pinned = None
+    n_all = len(allowed)
 
     def leg(nthreads, budget):
         oracle.voxelize(depth[: offsets[16]], offsets[:17], headers[:16], R=RES, n_threads=nthreads)  # warm
@@ -228,14 +239,25 @@ def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5):
             if dt >= budget:
                 return frames / dt, frames, dt, used
 
-    fps1, n1, t1, _ = leg(1, single_s)
-    fpsN, nN, tN, used = leg(threads, multi_s)
+    try:
+        fps1, n1, t1, _ = leg(1, single_s)
+        fps16, n16, t16, used16 = leg(min(16, n_all), multi_s)
+        fpsN, nN, tN, used = (fps16, n16, t16, used16) if n_all <= 16 else leg(n_all, all_s)
+    finally:
+        if pinned is not None:
+            try:
+                os.sched_setaffinity(0, pinned)
+            except OSError:
+                pass
     return {
         "value": round(fpsN, 1), "unit": "frames/s", "cores": int(used), "kind": "port",
         "sample": f"oracle/tsdf_oracle.c (C restatement of the reference math; the numba path itself is not "
                   f"runnable: no usable numba, no params.py) over the same 1024 synthetic frames: "
-                  f"{nN} frames in {tN:.2f} s on {used} OpenMP threads; single thread {n1} frames in {t1:.2f} s",
+                  f"{nN} frames in {tN:.2f} s on {used} OpenMP threads (= every CPU the process is allowed); "
+                  f"{n16} frames in {t16:.2f} s on {used16} threads; single thread {n1} frames in {t1:.2f} s",
         "single_thread_value": round(fps1, 1),
+        "threads16_value": round(fps16, 1), "threads16_cores": int(used16),
+        "allowed_cpus": n_all, "allowed_cpulist": _format_cpulist(allowed), "os_cpu_count": os.cpu_count(),
         "provenance": "a C/OpenMP PORT written for this project, orders of magnitude faster than anything the reference "
                       "itself can run on a CPU; the reference's own implementation is the Python loop below",
         "reference_python_loop_frames_per_s_per_core": round(1.0 / SURVEY_PY_LOOP["tsdf_f_full_320x240_s_per_frame"], 2),
@@ -910,6 +932,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "barrier": (("node (/dev/shm)" if node_barrier.ok else "collective") if dist is not None else "none (one process)"),
+            # self-describing for an N-rank run: what carried the process group ("nccl" IS RCCL on ROCm) and how many ranks
+            "dist_backend": (dist.get_backend() if dist is not None else None),
+            "dist_world_size": (dist.get_world_size() if dist is not None else 1),
             "config": {
                 "workload": "BASELINE configs[1]: batch 1024 synthetic 320x240 full-frame depth crops -> 32^3 "
                             "3-channel TSDF per GPU and launch, inputs resident in HBM; one step = "

@@ -111,9 +111,18 @@ __device__ unsigned long long g_stamps[kStampBlocks * kStampFrames * kStampSlots
     if ((threadIdx.x & (kGW - 1)) == 0 && blockIdx.x < kStampBlocks && (iter) < kStampFrames)                      \
       g_stamps[(blockIdx.x * kStampFrames + (iter)) * kStampSlots + (slot)] = (val);                 \
   } while (0)
+// per-wave stamps: every wave's lane 0 records when it enters (which = 0) and leaves (1) the voxel pass
+__device__ unsigned long long g_wstamps[kStampBlocks * kStampFrames * 16 * 2];
+#define TSDF_WSTAMP(iter, which)                                                                     \
+  do {                                                                                               \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < kStampBlocks && (iter) < kStampFrames)               \
+      g_wstamps[((blockIdx.x * kStampFrames + (iter)) * 16 + (threadIdx.x >> 6)) * 2 + (which)] =    \
+          __builtin_amdgcn_s_memrealtime();                                                          \
+  } while (0)
 #else
 #define TSDF_STAMP(iter, slot) do { } while (0)
 #define TSDF_STAMP_VAL(iter, slot, val) do { } while (0)
+#define TSDF_WSTAMP(iter, which) do { } while (0)
 #endif
 
 // ---- raw VALU min/max (no canonicalising v_max x,x,x in front; operands here are never NaN) ----
@@ -1079,10 +1088,36 @@ __device__ __forceinline__ double uniform64(double v) {  // a wave-uniform float
   return __hiloint2double(hi, lo);
 }
 
+// Dynamic tiles (tile_ctr != null; the one-group-per-CU instantiations, R >= 48).  With the static split a wave keeps
+// one slab of rows for the whole volume, and slabs differ 2.5x in cost: rows near the faces of the cube project past
+// the hand (every voxel rejected: ~100 instructions per wave tile), rows through its middle take the z and x/y terms
+// (~260).  The in-kernel stamps showed the lightest wave done after 57 us and the heaviest after 147 us of a frame's
+// voxel pass (profiles/r04/stamps_aug64.log).  Here a unit of work is (slab of 64/R4 rows) x (kDynChunk slices); the
+// waves draw units from a counter in LDS, heaviest slabs (the middle ones) first.  A unit is still "pure" — a wave
+// tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit rate — and a wave's stores are
+// still 1 KiB contiguous.
+#ifndef TSDF_DYN_TILES
+#define TSDF_DYN_TILES 1
+#endif
+#ifndef TSDF_DYN_CHUNK
+#define TSDF_DYN_CHUNK 8
+#endif
+constexpr int kDynChunk = TSDF_DYN_CHUNK;
+
+// unit number -> slab: middle-out (n_slab even: h-1, h, h-2, h+1, ...)
+__device__ __forceinline__ int dyn_slab(int rank, int n_slab) {
+  const int h = n_slab >> 1, k = rank >> 1;
+  const int s = (rank & 1) ? h + k : h - 1 - k;
+  return s < 0 ? 0 : (s >= n_slab ? n_slab - 1 : s);
+}
+
 template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                            const double *xf, const Tabs &tb, const SrcP src,
-                                           const GlobalOut out, const int tid, const int sb, const int se) {
+                                           const GlobalOut out, const int tid, const int sb, const int se,
+                                           int *tile_ctr = nullptr, int stamp_iter = 0) {
+  (void)stamp_iter;
+  TSDF_WSTAMP(stamp_iter, 0);
   if (se <= sb) return;  // (uniform) nothing to do; the end-slice lookups below assume one slice at least
   const double *fwd = xf;
   const LdsCD tabx = tb.atab, taby = tb.atab + 4 * R, tabz = tb.atab + 8 * R;
@@ -1115,7 +1150,28 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
   // (A wave's 64 groups of 4 voxels are one 64 x 4 tile of a slice at 64^3.  Narrower 32 x 8 tiles — fewer slices hold a
   // near voxel for them when the map rotates, 15 % fewer VALU instructions — measured +-0.2 % in a same-buffer paired A/B:
   // after this round's diet the pass is no longer bound by instruction issue.  Not kept.)
-  for (int gi = g0i; gi < G; gi += gstep) {
+  const bool dyn = TSDF_DYN_TILES && tile_ctr != nullptr && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0;  // uniform
+  const int n_slab = dyn ? R / (64 / R4) : 0;                      // slabs of 64/R4 rows: one wave tile per slice
+  const int n_chunk = (se - sb + kDynChunk - 1) / kDynChunk;
+  const int n_unit = n_slab * n_chunk;
+  auto draw = [&]() -> int {
+    int t = 0;
+    if ((tid & 63) == 0) t = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  int unit = dyn ? draw() : 0;
+  for (int gi = g0i;; gi += gstep) {
+    int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
+    if (dyn) {
+      if (unit >= n_unit) break;
+      const int rank = unit / n_chunk, c = unit - rank * n_chunk;
+      gi = dyn_slab(rank, n_slab) * 64 + (tid & 63);
+      zb = sb + c * kDynChunk;
+      ze = zb + kDynChunk < se ? zb + kDynChunk : se;
+      zs = 1;
+    } else if (gi >= G) {
+      break;
+    }
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
     const double ty0 = taby[4 * y], ty1 = taby[4 * y + 1], ty2 = taby[4 * y + 2];
@@ -1147,17 +1203,17 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     // (every rounding is), so its two end slices bound it; same sign and mid-range at both ends -> mid-range throughout.
     bool mild = mid_range(cam.focal, 0x1p-100, 0x1p100);
     {
-      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 4 * sb, thi = (LAYOUT == 0 ? tabz : tabx) + 4 * (se - 1);
+      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 4 * zb, thi = (LAYOUT == 0 ? tabz : tabx) + 4 * (ze - 1);
       const double s_lo = LAYOUT == 0 ? tlo[2] : tlo[2] + ty2, s_hi = LAYOUT == 0 ? thi[2] : thi[2] + ty2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const double za = pre[j][2] + s_lo, zb = pre[j][2] + s_hi;
-        mild = mild && mid_range(za, 0x1p-600, 0x1p600) && mid_range(zb, 0x1p-600, 0x1p600) && ((za > 0.0) == (zb > 0.0));
+        const double z_a = pre[j][2] + s_lo, z_b = pre[j][2] + s_hi;
+        mild = mild && mid_range(z_a, 0x1p-600, 0x1p600) && mid_range(z_b, 0x1p-600, 0x1p600) && ((z_a > 0.0) == (z_b > 0.0));
       }
     }
     auto slices = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
-    for (int sl = sb + s0; sl < se; sl += sstep) {
+    for (int sl = zb; sl < ze; sl += zs) {
       // ---- project the 4 voxels and gather their depths ----
       int ex[4], ry[4];
       float pd[4];
@@ -1240,7 +1296,9 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     } else {
       slices(std::false_type{});
     }
+    if (dyn) unit = draw();
   }
+  TSDF_WSTAMP(stamp_iter, 1);
 }
 
 
@@ -1329,6 +1387,7 @@ struct HelpReq {
 struct GroupCtl {
   int bar[kMaxGroups];
   int local_next;         // CU-local work queue (launches without a global queue word)
+  int tile_next;          // one-group instantiations: the voxel pass's unit counter (phase2_aug, dynamic tiles)
   int lock;               // TSDF_P2_LOCK builds: one group at a time between the extents barrier and the end of phase 2
   int help_for;           // 0: none; g+1: group g is asked to help with the frame in `help`
   int idle[kMaxGroups];
@@ -1825,6 +1884,9 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         if constexpr (kGroups == 2 && TSDF_TAIL_HELP) {
           if (gwave == 0 && lane == 0) ctl.hdr[group].pad = lds_load(&ctl.idle[group ^ 1]);
         }
+        if constexpr (kGroups == 1) {
+          if (gwave == 0 && lane == 0) lds_store(&ctl.tile_next, 0);   // ordered by the barrier below
+        }
         gsync();
         TSDF_STAMP(kGroups * iter + group, 8);
         bool helped = false;  // group-uniform
@@ -1870,7 +1932,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
             }
           }
           if constexpr (AUG) {
-            phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R);
+            phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R,
+                                    kGroups == 1 ? &ctl.tile_next : nullptr, kGroups * iter + group);
           } else {
             phase2<LAYOUT, kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
           }
@@ -2380,11 +2443,20 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
   return hipGetLastError();
 }
 
+// -DTSDF_DEV_ONLY64 (experiment builds, never the product): only the 64^3 [c,z,y,x] instantiations are compiled —
+// 25 s instead of 3 min per variant; every other call returns hipErrorInvalidValue.
 template <int LAYOUT, bool AUG>
 hipError_t launch_r(hipStream_t s, KArgs &a, int dev) {
+#ifdef TSDF_DEV_ONLY64
+  if constexpr (LAYOUT == 0) {
+    if (a.R == 64) return launch<64, LAYOUT, AUG, false>(s, a, dev);
+  }
+  return hipErrorInvalidValue;
+#else
   if (a.R == 32) return launch<32, LAYOUT, AUG, false>(s, a, dev);
   if (a.R == 64) return launch<64, LAYOUT, AUG, false>(s, a, dev);
   return launch<0, LAYOUT, AUG, false>(s, a, dev);
+#endif
 }
 
 struct RunOpts {
@@ -2459,11 +2531,18 @@ int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const
   a.pixmap = o.pixmap;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipError_t e;
+#ifdef TSDF_DEV_ONLY64
+  if (o.pixmap) return TSDF_ERR_INVALID_ARG;
+#endif
   if (o.pixmap) {
+#ifndef TSDF_DEV_ONLY64
     if (layout == TSDF_LAYOUT_CZYX)
       e = R == 32 ? launch<32, 0, false, true>(s, a, dev) : launch<0, 0, false, true>(s, a, dev);
     else
       e = R == 32 ? launch<32, 1, false, true>(s, a, dev) : launch<0, 1, false, true>(s, a, dev);
+#else
+    e = hipErrorInvalidValue;
+#endif
   } else if (o.xforms) {
     e = layout == TSDF_LAYOUT_CZYX ? launch_r<0, true>(s, a, dev) : launch_r<1, true>(s, a, dev);
   } else {
@@ -2718,6 +2797,14 @@ int tsdf_debug_read_stamps(unsigned long long *host_out, int count) {
   if (count > total) count = total;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * count) != hipSuccess)
+    return -1;
+  return count;
+}
+int tsdf_debug_read_wstamps(unsigned long long *host_out, int count) {
+  const int total = kStampBlocks * kStampFrames * 16 * 2;
+  if (count > total) count = total;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * count) != hipSuccess)
     return -1;
   return count;
 }

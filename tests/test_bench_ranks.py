@@ -119,6 +119,7 @@ def test_bench_multi_rank_path_runs_under_torchrun_with_gloo(tmp_path, world):
     assert j["n_gpus"] == world and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["rehearsal"] is True and "dry_run" in j and j["barrier"].startswith("node")
     assert j["unit"] == "frames/s" and j["metric"].startswith("depth frames/sec")
+    assert j["dist_backend"] == "gloo" and j["dist_world_size"] == world   # (an RCCL run says "nccl")
     cfg = j["config"]
     assert cfg["frames_per_launch"] == 1024 and cfg["launches_per_step"] == 16
     # value is total frames over the slowest rank's wall time; ms_per_step * steps is that wall time

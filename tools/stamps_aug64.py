@@ -27,6 +27,10 @@ L.tsdf_voxelize_aug_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ct
                                     vp, vp, vp]
 L.tsdf_debug_read_stamps.restype = ctypes.c_int
 L.tsdf_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+HAVE_W = hasattr(L, "tsdf_debug_read_wstamps")
+if HAVE_W:
+    L.tsdf_debug_read_wstamps.restype = ctypes.c_int
+    L.tsdf_debug_read_wstamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = torch.device("cuda:0")
 N = int(os.environ.get("PROF_FRAMES", "1024"))
 R = int(os.environ.get("PROF_R", "64"))
@@ -105,3 +109,16 @@ for rep in range(int(os.environ.get("STAMPS_REPS", "2"))):
     pro = share[:9].sum()
     print(f"   => prologue (everything but the voxel pass) {pro:.1f} %, voxel pass {share[9]:.1f} %; "
           f"mean per frame: prologue {tot[:9].sum() / nfr:.1f} us, voxel pass {tot[9] / nfr:.1f} us")
+    if HAVE_W and AUG:
+        wb = np.zeros(BL * FR * 16 * 2, np.uint64)
+        assert L.tsdf_debug_read_wstamps(wb.ctypes.data, wb.size) == wb.size
+        w = wb.reshape(BL, FR, 16, 2).astype(np.int64)[:256]
+        lvw = live & (w[:, :, :, 0].min(axis=2) >= t0)
+        beg = w[:, :, :, 0] - w[:, :, :, 0].min(axis=2, keepdims=True)     # wave's entry after the CU's first wave
+        dur = (w[:, :, :, 1] - w[:, :, :, 0])[lvw] / 100.0               # [frames, 16]
+        endrel = (w[:, :, :, 1] - w[:, :, :, 0].min(axis=2, keepdims=True))[lvw] / 100.0
+        print("   voxel pass per wave (us, median over all live frames): wave: in-pass time | leaves after the pass began")
+        print("      " + "  ".join(f"w{k:02d} {np.median(dur[:, k]):5.1f}|{np.median(endrel[:, k]):5.1f}" for k in range(16)))
+        span = endrel.max(axis=1)
+        print(f"      pass length (last wave out) median {np.median(span):.1f} us; first wave out median {np.median(endrel.min(axis=1)):.1f} us; "
+              f"mean wave busy {100 * np.mean(dur.sum(axis=1) / (16 * span)):.0f} % of the pass")
