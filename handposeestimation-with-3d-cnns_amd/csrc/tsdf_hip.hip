@@ -939,13 +939,87 @@ __device__ __forceinline__ float gather_rel<LdsSrc>(const LdsSrc src, const VoxK
   return gather_px(src, k, relx << 2, rely, ent, inb);   // a column outside the row's window (or the box) fails its test
 }
 
+// Dynamic tiles (tile_ctr != null; the one-group-per-CU instantiations, R >= 48).  With the static split a wave keeps
+// one slab of rows for the whole volume, and slabs differ 2.5x in cost: rows near the faces of the cube project past
+// the hand (every voxel rejected: ~100 instructions per wave tile), rows through its middle take the z and x/y terms
+// (~260).  The in-kernel stamps showed the lightest wave done after 57 us and the heaviest after 147 us of a frame's
+// voxel pass (profiles/r04/stamps_aug64.log).  Here a unit of work is (slab of 64/R4 rows) x (kDynChunk slices); the
+// waves draw units from a counter in LDS, heaviest slabs (the middle ones) first.  A unit is still "pure" — a wave
+// tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit rate — and a wave's stores are
+// still 1 KiB contiguous.
+#ifndef TSDF_DYN_TILES
+#define TSDF_DYN_TILES 1
+#endif
+#ifndef TSDF_DYN_CHUNK
+#define TSDF_DYN_CHUNK 8
+#endif
+constexpr int kDynChunk = TSDF_DYN_CHUNK;
+// Two tiers: the last TSDF_DYN_TAIL_SLICES slices of the pass are handed out in chunks of TSDF_DYN_TAIL_CHUNK, after all
+// the big units — the waves reach the pass's closing barrier within one SMALL unit of each other.
+#ifndef TSDF_DYN_TAIL_CHUNK
+#define TSDF_DYN_TAIL_CHUNK TSDF_DYN_CHUNK
+#endif
+#ifndef TSDF_DYN_TAIL_SLICES
+#define TSDF_DYN_TAIL_SLICES 0
+#endif
+constexpr int kDynTailChunk = TSDF_DYN_TAIL_CHUNK, kDynTailSlices = TSDF_DYN_TAIL_SLICES;
+
+// The unit plan of one pass over slices [sb, se) with n_slab slabs: unit -> (slab, first slice, end slice).
+struct DynPlan {
+  int n_slab, sb, split, se;       // big chunks cover [sb, split), small ones [split, se)
+  int n_big, n_small, n_unit;      // chunks per slab in each tier; units in all
+};
+__device__ __forceinline__ DynPlan dyn_plan(int n_slab, int sb, int se) {
+  DynPlan p;
+  p.n_slab = n_slab;
+  p.sb = sb;
+  p.se = se;
+  int tail = kDynTailSlices < se - sb ? kDynTailSlices : 0;
+  if (kDynTailChunk >= kDynChunk) tail = 0;
+  p.split = se - tail;
+  p.n_big = (p.split - sb + kDynChunk - 1) / kDynChunk;
+  p.n_small = (tail + kDynTailChunk - 1) / kDynTailChunk;
+  p.n_unit = n_slab * (p.n_big + p.n_small);
+  return p;
+}
+__device__ __forceinline__ int dyn_units_of(int R, int sb, int se) {   // 0: the resolution has no dynamic units
+  const int R4 = R / 4;
+  if (!(TSDF_DYN_TILES && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0)) return 0;
+  return dyn_plan(R / (64 / R4), sb, se).n_unit;
+}
+__device__ __forceinline__ int dyn_slab(int rank, int n_slab);
+__device__ __forceinline__ void dyn_unit(const DynPlan &p, int unit, int &slab, int &zb, int &ze) {
+  const int big_units = p.n_slab * p.n_big;
+  if (unit < big_units) {
+    const int rank = unit / p.n_big, c = unit - rank * p.n_big;
+    slab = dyn_slab(rank, p.n_slab);
+    zb = p.sb + c * kDynChunk;
+    ze = zb + kDynChunk < p.split ? zb + kDynChunk : p.split;
+  } else {
+    const int u = unit - big_units;
+    const int rank = u / p.n_small, c = u - rank * p.n_small;
+    slab = dyn_slab(rank, p.n_slab);
+    zb = p.split + c * kDynTailChunk;
+    ze = zb + kDynTailChunk < p.se ? zb + kDynTailChunk : p.se;
+  }
+}
+
+// unit number -> slab: middle-out (n_slab even: h-1, h, h-2, h+1, ...)
+__device__ __forceinline__ int dyn_slab(int rank, int n_slab) {
+  const int h = n_slab >> 1, k = rank >> 1;
+  const int s = (rank & 1) ? h + k : h - 1 - k;
+  return s < 0 ? 0 : (s >= n_slab ? n_slab - 1 : s);
+}
+
 // The voxel pass over slow-axis slices [sb, se).  T threads take part (tid in [0, T)): T = kGW when a group
 // works alone, 2*kGW when the CU's other group helps (its threads come in as kGW + gtid), kWG in the split
 // kernel.
 template <int LAYOUT, int T, bool DBG, class SrcP>
 __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R, const Tabs &tb,
                                        const bool use_tab, const SrcP src, const GlobalOut out, const int tid,
-                                       const int sb, const int se, const PixMapK &pm) {
+                                       const int sb, const int se, const PixMapK &pm, int *tile_ctr = nullptr,
+                                       int unit_end = -1) {
+  if (se <= sb) return;
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1];
   const int R4 = R / 4;
@@ -965,7 +1039,28 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
     s0 = 0;
     sstep = 1;
   }
-  for (int gi = g0; gi < G; gi += gstep) {
+  // dynamic units (see above): (slab of 64/R4 rows) x (kDynChunk slices) drawn from a counter in LDS
+  const bool dyn = TSDF_DYN_TILES && tile_ctr != nullptr && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0;  // uniform
+  const int n_slab = dyn ? R / (64 / R4) : 0;
+  const DynPlan plan = dyn_plan(n_slab, sb, se);
+  auto draw = [&]() -> int {
+    int t = 0;
+    if ((tid & 63) == 0) t = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  int unit = dyn ? draw() : 0;
+  for (int gi = g0;; gi += gstep) {
+    int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
+    if (dyn) {
+      if (unit >= (unit_end >= 0 && unit_end < plan.n_unit ? unit_end : plan.n_unit)) break;
+      int slab;
+      dyn_unit(plan, unit, slab, zb, ze);
+      gi = slab * 64 + (tid & 63);
+      zs = 1;
+      unit = draw();   // (the next unit's number travels while this one is computed)
+    } else if (gi >= G) {
+      break;
+    }
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
     const double vy = oy + (double)y * vl;                                  // :27
@@ -978,8 +1073,8 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
         vx[j] = ox + (double)(f4i + j) * vl;                                // :26
         vxs[j] = vx[j] * vk.it;
       }
-      for (int z = sb + s0; z < se; z += sstep) {
-        const ZEntry ze = load_z(tb.ztab + z);
+      for (int z = zb; z < ze; z += zs) {
+        const ZEntry zen = load_z(tb.ztab + z);
         int ex[4], ry[4];
         unsigned ent[4];
         if (use_tab) {
@@ -989,14 +1084,14 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
           ry[0] = IsLds<SrcP>::value ? (int)tb.pyrow[z * R + y] : (int)ent[0];
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ex[j] = col_code(project_rel(vx[j], ze.q, cam.cx, vk.px0, vk.dx));  // :31
-          ry[0] = project_rel(-vy, ze.q, cam.cy, vk.py0, vk.dy);                                 // :32
+          for (int j = 0; j < 4; ++j) ex[j] = col_code(project_rel(vx[j], zen.q, cam.cx, vk.px0, vk.dx));  // :31
+          ry[0] = project_rel(-vy, zen.q, cam.cy, vk.py0, vk.dy);                                 // :32
           ent[0] = row_entry<SrcP>(tb, ry[0]);
         }
         ry[1] = ry[2] = ry[3] = ry[0];
         ent[1] = ent[2] = ent[3] = ent[0];
-        const double vzs[4] = {ze.vzs, ze.vzs, ze.vzs, ze.vzs};
-        const float negthr[4] = {ze.negthr, ze.negthr, ze.negthr, ze.negthr};
+        const double vzs[4] = {zen.vzs, zen.vzs, zen.vzs, zen.vzs};
+        const float negthr[4] = {zen.negthr, zen.negthr, zen.negthr, zen.negthr};
         f4 o0, o1, o2;
         const unsigned okm = voxel_values4(ex, ry, ent, vxs, vys, vzs, negthr, vk, src, o0, o1, o2);
         const int64_t e = ((int64_t)z * R + y) * R + f4i;                   // o[c][z][y][x] :70-72
@@ -1017,10 +1112,10 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
       unsigned ent[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const ZEntry ze = load_z(tb.ztab + f4i + j);
-        q[j] = ze.q;
-        vzs[j] = ze.vzs;
-        negthr[j] = ze.negthr;
+        const ZEntry zen = load_z(tb.ztab + f4i + j);
+        q[j] = zen.q;
+        vzs[j] = zen.vzs;
+        negthr[j] = zen.negthr;
       }
       if (use_tab) {
         const u4v e = *(LdsU4)(tb.pytab + y * R + f4i);
@@ -1039,7 +1134,7 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
           ent[j] = row_entry<SrcP>(tb, ry[j]);
         }
       }
-      for (int x = sb + s0; x < se; x += sstep) {
+      for (int x = zb; x < ze; x += zs) {
         const double vx = ox + (double)x * vl;
         const double vx1 = vx * vk.it;
         const double vxs[4] = {vx1, vx1, vx1, vx1};
@@ -1088,34 +1183,11 @@ __device__ __forceinline__ double uniform64(double v) {  // a wave-uniform float
   return __hiloint2double(hi, lo);
 }
 
-// Dynamic tiles (tile_ctr != null; the one-group-per-CU instantiations, R >= 48).  With the static split a wave keeps
-// one slab of rows for the whole volume, and slabs differ 2.5x in cost: rows near the faces of the cube project past
-// the hand (every voxel rejected: ~100 instructions per wave tile), rows through its middle take the z and x/y terms
-// (~260).  The in-kernel stamps showed the lightest wave done after 57 us and the heaviest after 147 us of a frame's
-// voxel pass (profiles/r04/stamps_aug64.log).  Here a unit of work is (slab of 64/R4 rows) x (kDynChunk slices); the
-// waves draw units from a counter in LDS, heaviest slabs (the middle ones) first.  A unit is still "pure" — a wave
-// tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit rate — and a wave's stores are
-// still 1 KiB contiguous.
-#ifndef TSDF_DYN_TILES
-#define TSDF_DYN_TILES 1
-#endif
-#ifndef TSDF_DYN_CHUNK
-#define TSDF_DYN_CHUNK 8
-#endif
-constexpr int kDynChunk = TSDF_DYN_CHUNK;
-
-// unit number -> slab: middle-out (n_slab even: h-1, h, h-2, h+1, ...)
-__device__ __forceinline__ int dyn_slab(int rank, int n_slab) {
-  const int h = n_slab >> 1, k = rank >> 1;
-  const int s = (rank & 1) ? h + k : h - 1 - k;
-  return s < 0 ? 0 : (s >= n_slab ? n_slab - 1 : s);
-}
-
 template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                            const double *xf, const Tabs &tb, const SrcP src,
                                            const GlobalOut out, const int tid, const int sb, const int se,
-                                           int *tile_ctr = nullptr, int stamp_iter = 0) {
+                                           int *tile_ctr = nullptr, int stamp_iter = 0, int unit_end = -1) {
   (void)stamp_iter;
   TSDF_WSTAMP(stamp_iter, 0);
   if (se <= sb) return;  // (uniform) nothing to do; the end-slice lookups below assume one slice at least
@@ -1152,8 +1224,7 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
   // after this round's diet the pass is no longer bound by instruction issue.  Not kept.)
   const bool dyn = TSDF_DYN_TILES && tile_ctr != nullptr && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0;  // uniform
   const int n_slab = dyn ? R / (64 / R4) : 0;                      // slabs of 64/R4 rows: one wave tile per slice
-  const int n_chunk = (se - sb + kDynChunk - 1) / kDynChunk;
-  const int n_unit = n_slab * n_chunk;
+  const DynPlan plan = dyn_plan(n_slab, sb, se);
   auto draw = [&]() -> int {
     int t = 0;
     if ((tid & 63) == 0) t = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1163,12 +1234,12 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
   for (int gi = g0i;; gi += gstep) {
     int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
     if (dyn) {
-      if (unit >= n_unit) break;
-      const int rank = unit / n_chunk, c = unit - rank * n_chunk;
-      gi = dyn_slab(rank, n_slab) * 64 + (tid & 63);
-      zb = sb + c * kDynChunk;
-      ze = zb + kDynChunk < se ? zb + kDynChunk : se;
+      if (unit >= (unit_end >= 0 && unit_end < plan.n_unit ? unit_end : plan.n_unit)) break;
+      int slab;
+      dyn_unit(plan, unit, slab, zb, ze);
+      gi = slab * 64 + (tid & 63);
       zs = 1;
+      unit = draw();   // (the next unit's number travels while this one is computed)
     } else if (gi >= G) {
       break;
     }
@@ -1296,7 +1367,6 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     } else {
       slices(std::false_type{});
     }
-    if (dyn) unit = draw();
   }
   TSDF_WSTAMP(stamp_iter, 1);
 }
@@ -1387,7 +1457,13 @@ struct HelpReq {
 struct GroupCtl {
   int bar[kMaxGroups];
   int local_next;         // CU-local work queue (launches without a global queue word)
-  int tile_next;          // one-group instantiations: the voxel pass's unit counter (phase2_aug, dynamic tiles)
+  int tile_next;          // one-group instantiations: the voxel pass's unit counter (dynamic tiles)
+  int pbar;               // pipelined kernel: barrier of the producer waves
+  int next_ok;            // ... the next frame's rows were streamed (its header was consistent)
+  FrameHdr next_hdr;      // ... the next frame (frame = -1: none)
+  float next_fin[16];     // ... and its 10 extents
+  FrameHdr saved_hdr;     // phase-shifted start: the CU's first frame, whose last units are voxelized at the very end
+  float saved_fin[16];
   int lock;               // TSDF_P2_LOCK builds: one group at a time between the extents barrier and the end of phase 2
   int help_for;           // 0: none; g+1: group g is asked to help with the frame in `help`
   int idle[kMaxGroups];
@@ -1759,6 +1835,14 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
   cap.on = false;
 
   const int n_static = gridDim.x * kGroups;  // frames handed out by position (the first one per group)
+#ifdef TSDF_START_STAGGER
+  // experiment: CUs start in four phase groups TSDF_START_STAGGER us apart (are the CUs' store-less prologues in step?)
+  if constexpr (kGroups == 1) {
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (TSDF_START_STAGGER) * 100ull;
+    while (__builtin_amdgcn_s_memrealtime() - t_in < wait) __builtin_amdgcn_s_sleep(20);
+  }
+#endif
 
   int iter = 0;
   (void)iter;
@@ -1998,6 +2082,270 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         run2(hsrc);
       }
     }
+  }
+}
+
+// ---- pipelined kernel: one 1024-thread group per CU (R >= 48) -----------------------------------------------------
+// At 64^3 a frame's voxel pass is bound by its stores (3.1 MB per frame; the stamps show the CU's four SIMDs draining
+// their waves one after the other at exactly the chip's fill rate / 256), and everything else a frame needs — ticket,
+// header, row stream, extents barrier, glue — is a chain of memory latencies during which the CU stores NOTHING.  With
+// every CU starting at once and frames costing about the same, the CUs stay in step: the whole chip stops writing for
+// ~30 us per frame (profiles/r04/stamps_aug64.log: 17 % of the launch).  So the next frame's chain runs DURING the
+// current frame's voxel pass: kPipeProducers waves draw the next ticket, fetch its header, stream its rows and reduce
+// its extents (for the augmented form that includes the per-pixel transform), then join the voxel pass — which hands
+// out (slab x slice-chunk) units dynamically, so it does not matter when they arrive.  Between two voxel passes only
+// glue, the staging copy (L2 hits: the rows were just read) and the tables remain: ~6 us instead of ~35.
+// The LDS pool is still single: staging starts when the previous pass has left it.
+#ifndef TSDF_PIPE
+#define TSDF_PIPE 1
+#endif
+#ifndef TSDF_PIPE_PRODUCERS
+#define TSDF_PIPE_PRODUCERS 4
+#endif
+constexpr int kPipeProducers = TSDF_PIPE_PRODUCERS;
+
+template <int RT, int LAYOUT, bool AUG, bool DBG>
+__global__ __launch_bounds__(kWG) void tsdf_pipe_kernel(const KArgs a, const float *__restrict__ in_depth,
+                                                        const int64_t *__restrict__ in_offsets,
+                                                        const int32_t *__restrict__ in_headers,
+                                                        const double *__restrict__ in_xforms) {
+  [[maybe_unused]] constexpr int kGW = kWG;  // (the stamp macros' group size)
+  constexpr int kGWaves = kWG / 64, kNP = kPipeProducers;
+  static_assert(kNP >= 1 && kNP <= kGWaves, "producer waves");
+  using L = Lds<RT, AUG, 1>;
+  __shared__ typename L::Block lds;
+
+  const int R = RT ? RT : a.R;
+  const CamK &cam = a.cam;
+  const int n = a.n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto &pg = lds.pg[0];
+  GroupCtl &ctl = lds.ctl;
+
+  if (tid == 0) {
+    ctl.bar[0] = 0;
+    ctl.pbar = 0;
+    ctl.local_next = 1;
+    ctl.tile_next = 0;
+  }
+  __syncthreads();
+  int bar_target = 0, pbar_target = 0;
+  auto gsync = [&]() { group_barrier<kGWaves>(&ctl.bar[0], bar_target); };
+  auto psync = [&]() { group_barrier<kNP>(&ctl.pbar, pbar_target); };
+
+  Capture cap;   // (phase1_extents' capture argument: never on here)
+  cap.pool = (LdsF)lds.pool;
+  cap.rowtab = (LdsU)pg.rowtab;
+  cap.fail = (LdsI)&ctl.cap_fail[0];
+  cap.cap4 = 0;
+  cap.base4 = 0;
+  cap.on = false;
+
+  // The next frame of this CU (one wave calls this): the first one by position, the rest from the launch's queue word
+  // — or, without one, from the CU's own stride (see the fused kernel).
+  auto draw_frame = [&](bool first, FrameHdr &m) {
+    int fr;
+    if (first) {
+      fr = blockIdx.x;
+    } else if (a.queue) {
+      unsigned int t = 0;
+      if (lane == 0) {
+        t = atomicAdd(a.queue, 1u);
+        if (t == (unsigned int)(n - 1)) __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fr = (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane(t);
+    } else {
+      int t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(&ctl.local_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int64_t f64i = (int64_t)blockIdx.x + (int64_t)gridDim.x * __builtin_amdgcn_readfirstlane(t);
+      fr = f64i < n ? (int)f64i : n;
+    }
+    m.frame = fr < n ? fr : -1;
+    m.l = m.t = m.r = m.b = m.pad = 0;
+    m.off0 = m.off1 = m.src = 0;
+    if (fr < n) fetch_header(a, in_offsets, in_headers, fr, m);
+  };
+
+  // ---- the CU's first frame: all 16 waves stream its rows ----
+  if (wave == 0) {
+    FrameHdr m;
+    draw_frame(true, m);
+    if (lane == 0) ctl.hdr[0] = m;
+  }
+  gsync();
+  FrameHdr fh = ctl.hdr[0];
+  int frame = __builtin_amdgcn_readfirstlane(fh.frame);
+  if (frame < 0) return;
+  TSDF_STAMP(0, 0);
+  Frame f;
+  bool hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
+  float fin[kExt];
+#pragma unroll
+  for (int i = 0; i < kExt; ++i) fin[i] = i < 5 ? TSDF_INF : -TSDF_INF;
+  if (hdr_ok)
+    phase1_extents<kGWaves, AUG, false>(f, cam, 0, f.bh, pg.red, fin, wave, gsync, cap, 0,
+                                        AUG ? in_xforms + 24 * (int64_t)frame : nullptr);
+
+  // Phase-shifted start (TSDF_PHASE_SHIFT): the CUs form four phase groups; group g voxelizes only the first (4-g)/4 of
+  // its FIRST frame's units, goes on with its other frames, and finishes that frame's remaining units at the very end.
+  // Every CU still does the same work and ends at the same time, but the groups' store-less stretches (header, rows,
+  // extents, staging) no longer coincide across the chip.
+#ifndef TSDF_PHASE_SHIFT
+#define TSDF_PHASE_SHIFT 0
+#endif
+  const int ph_group = (blockIdx.x >> 3) & 3;
+  const int ph_units = dyn_units_of(R, 0, R);
+  int rem_state = (TSDF_PHASE_SHIFT && ph_group > 0 && ph_units > 0 && !a.aabb_only && a.tsdf && n >= 2 * (int)gridDim.x)
+                      ? 1 : 0;   // 1: the first frame is cut short and its remainder still has to be scheduled
+  const int ph_cut = ph_units * (4 - ph_group) / 4;
+
+  for (int iter = 0;; ++iter) {
+    // ---- here every thread holds the current frame: fh, frame, f, hdr_ok, fin ----
+    float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
+    const bool want_vol = !a.aabb_only && out;
+    const bool is_rem = fh.pad == 1;              // this pass: the saved first frame's remaining units
+    int u_begin = 0, u_end = -1;
+    if (iter == 0 && rem_state) {
+      u_end = ph_cut;
+      if (wave == 0) {
+        if (lane == 0) ctl.saved_hdr = fh;
+        if (lane < kExt) {
+          float v = fin[0];
+#pragma unroll
+          for (int i = 1; i < kExt; ++i) v = (lane == i) ? fin[i] : v;
+          ctl.saved_fin[lane] = v;
+        }
+      }
+    }
+    if (is_rem) u_begin = ph_cut;
+    const double *xf = AUG ? in_xforms + 24 * (int64_t)frame : nullptr;
+    int status = TSDF_FRAME_OK;
+    Aabb ab;
+    ab.any = false;
+    ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
+    ab.c0 = ab.r0 = 0;
+    ab.c1 = ab.r1 = -1;
+    Grid g;
+    g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
+    g.max_l = g.voxel_len = g.trunc = 0.f;
+    g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
+    if (!hdr_ok) {
+      status = TSDF_FRAME_BAD_HEADER;
+    } else {
+      ab = aabb_from_extents(fin);
+      place_grid(ab, R, cam, a.grid_in, frame, g, status);
+    }
+    TSDF_STAMP(iter, 4);
+    if (!is_rem) {
+      if (tid == 0) write_frame_outputs(a, frame, g, ab, status);
+      write_labels(a, frame, fh.src, g, status, xf, tid, kWG);
+    }
+
+    const bool do_vox = want_vol && status == TSDF_FRAME_OK;   // uniform
+    if (want_vol && !do_vox && !is_rem) {
+      zero_volume(out, R, tid, kWG, 0, 1);
+      if constexpr (DBG) {
+        if (a.pixmap)
+          for (int i = tid; i < R * R * R; i += kWG) a.pixmap[(int64_t)frame * R * R * R + i] = -1;
+      }
+    }
+    int vt = tid;
+    asm volatile("" : "+v"(vt));   // (see the fused kernel: keeps per-thread constants out of the row stream's registers)
+    int mode = kFillGlobal;
+    VoxK vk;
+    bool use_tab = false;
+    if (do_vox) {
+      const int sc0 = DBG ? 0 : ab.c0, sr0 = DBG ? 0 : ab.r0;
+      const int sw = DBG ? f.bw : ab.c1 - ab.c0 + 1, sh = DBG ? f.bh : ab.r1 - ab.r0 + 1;
+      const int sw4 = (sw + 3) & ~3;
+      const bool staged = (int64_t)sw4 * sh <= L::kPoolFloats;  // uniform
+      if (staged) {
+        mode = kFillRect;
+        stage_rect_dma<kGWaves>(lds.pool, f, fh.off1 - fh.off0, sc0, sr0, sh, sw4, wave, lane);
+      }
+      vk = make_voxk(cam, g, f, ab, mode, DBG, sw4);
+      use_tab = !AUG && R <= kTabR;
+      TSDF_STAMP(iter, 5);
+      fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, false, xf, vt, kWG);
+      TSDF_STAMP(iter, 6);
+      if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TSDF_STAMP(iter, 7);
+    }
+    if (wave == 0 && lane == 0) lds_store(&ctl.tile_next, u_begin);
+    gsync();   // tables, staged pixels and the unit counter are in place
+    TSDF_STAMP(iter, 8);
+
+    // ---- producers: the NEXT frame's ticket, header, rows and extents, while the others voxelize ----
+    if (wave < kNP) {
+      if (wave == 0) {
+        FrameHdr m;
+        if (is_rem) {            // the queue already said "empty" once: it must not be asked again (ticket accounting)
+          m.frame = -1;
+          m.l = m.t = m.r = m.b = m.pad = 0;
+          m.off0 = m.off1 = m.src = 0;
+        } else {
+          draw_frame(false, m);
+          if (m.frame < 0 && rem_state) {
+            m = ctl.saved_hdr;
+            m.pad = 1;
+          }
+        }
+        if (lane == 0) ctl.next_hdr = m;
+      }
+      psync();
+      const FrameHdr nh = ctl.next_hdr;
+      const int nframe = __builtin_amdgcn_readfirstlane(nh.frame);
+      if (nframe >= 0 && __builtin_amdgcn_readfirstlane(nh.pad) == 1) {
+        if (wave == 0 && lane < kExt) ctl.next_fin[lane] = ctl.saved_fin[lane];
+      } else if (nframe >= 0) {
+        Frame nf;
+        const bool ok = frame_from_header(nh, in_depth, a.depth_len, nf);   // uniform
+        if (ok) {
+          float nfin[kExt];
+          phase1_extents<kNP, AUG, false>(nf, cam, 0, nf.bh, pg.red, nfin, wave, psync, cap, iter + 1,
+                                          AUG ? in_xforms + 24 * (int64_t)nframe : nullptr);
+          if (wave == 0 && lane < kExt) {
+            float v = nfin[0];
+#pragma unroll
+            for (int i = 1; i < kExt; ++i) v = (lane == i) ? nfin[i] : v;
+            ctl.next_fin[lane] = v;
+          }
+        }
+      }
+      TSDF_STAMP(iter, 11);
+    }
+    // ---- the voxel pass (every wave; the producers join when their rows are done) ----
+    if (do_vox) {
+      const Tabs tb = make_tabs(pg);
+      PixMapK pm;
+      pm.out = DBG && a.pixmap ? (GlobalPix)(a.pixmap + (int64_t)frame * R * R * R) : (GlobalPix) nullptr;
+      pm.bw = f.bw;
+      pm.dc = vk.px0 - f.l;
+      pm.dr = vk.py0 - f.t;
+      auto run2 = [&](auto src) {
+        if constexpr (AUG) {
+          phase2_aug<LAYOUT, kWG>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R, &ctl.tile_next, iter, u_end);
+        } else {
+          phase2<LAYOUT, kWG, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm, &ctl.tile_next, u_end);
+        }
+      };
+      if (mode == kFillRect) {
+        run2(LdsRect{(LdsSrc)lds.pool});
+      } else {
+        run2((GlobalSrc)(f.depth + vk.base));
+      }
+    }
+    TSDF_STAMP(iter, 9);
+    gsync();   // the pass has left the pool and the tables; the next frame's record is complete
+    fh = ctl.next_hdr;
+    frame = __builtin_amdgcn_readfirstlane(fh.frame);
+    if (frame < 0) break;
+    if (__builtin_amdgcn_readfirstlane(fh.pad) == 1) rem_state = 0;   // the remainder is scheduled now
+    TSDF_STAMP(iter + 1, 0);
+    hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
+#pragma unroll
+    for (int i = 0; i < kExt; ++i) fin[i] = ctl.next_fin[i];
   }
 }
 
@@ -2429,8 +2777,13 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
   auto fused = [&](auto groups_tag) {
     constexpr int G = decltype(groups_tag)::value;
     a.queue = a.n > grid * G ? queue_word(dev, s) : nullptr;  // no dynamic frames: no word needed
-    hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG, G>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
-                       a.headers, a.xforms);
+    if constexpr (G == 1 && TSDF_PIPE && !kCaptureFill) {
+      hipLaunchKernelGGL((tsdf_pipe_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
+                         a.headers, a.xforms);
+    } else {
+      hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG, G>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
+                         a.headers, a.xforms);
+    }
   };
   if constexpr (RT != 0) {
     fused(std::integral_constant<int, groups_for(RT)>{});
