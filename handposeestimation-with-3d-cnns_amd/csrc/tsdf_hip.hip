@@ -1231,9 +1231,24 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     return __builtin_amdgcn_readfirstlane(t);
   };
   int unit = dyn ? draw() : 0;
+#ifndef TSDF_TILE_ORDER
+#define TSDF_TILE_ORDER 0
+#endif
+  // TSDF_TILE_ORDER 1 (experiment): no counter — all waves walk the slabs together (middle-out), wave w takes slices
+  // w, w+16, w+32, ... of the slab: equal work by construction, and the store order tools/probes/vol_store_probe.hip
+  // found best ("I": the 16 waves on 16 consecutive slices of one slab).
+  const bool walk = TSDF_TILE_ORDER == 1 && tile_ctr != nullptr && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0;
+  int walk_k = 0;
   for (int gi = g0i;; gi += gstep) {
     int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
-    if (dyn) {
+    if (walk) {
+      const int ns = R / (64 / R4);
+      if (walk_k >= ns) break;
+      gi = dyn_slab(walk_k, ns) * 64 + (tid & 63);
+      zb = sb + (tid >> 6);
+      zs = T / 64;
+      ++walk_k;
+    } else if (dyn) {
       if (unit >= (unit_end >= 0 && unit_end < plan.n_unit ? unit_end : plan.n_unit)) break;
       int slab;
       dyn_unit(plan, unit, slab, zb, ze);
