@@ -346,6 +346,15 @@ class HipBackend:
     def elapsed_ms(self, a, b):
         return a.elapsed_time(b)
 
+    def kernel_name(self, n, res=RES):
+        """The instantiation the library launches for this batch, from the library itself (tsdf_describe_launch)."""
+        import ctypes
+        L = self.pkg._lib.load()
+        buf = ctypes.create_string_buffer(160)
+        with torch.cuda.device(self.dev):
+            rc = L.tsdf_describe_launch(int(n), int(res), 0, 0, buf, 160)
+        return buf.value.decode() if rc == 0 else f"unknown (tsdf_describe_launch returned {rc})"
+
     def pci(self):
         p = torch.cuda.get_device_properties(self.dev)
         try:
@@ -388,16 +397,42 @@ class HostStub:
     def elapsed_ms(self, a, b):
         return (b[0] - a[0]) * 1e3
 
+    def kernel_name(self, n, res=RES):
+        return "host stub (no kernel)"
+
     def pci(self):
         return None
 
 
-def _time_launches(fn, k, warm=3):
-    """Mean time of k back-to-back launches (us), HIP events on the current stream."""
+def _time_launches(fn, k, warm=3, warm_ms=40.0, cold=None):
+    """Mean time of k back-to-back launches (us), HIP events on the current stream, at STEADY STATE: after the `warm`
+    launches the workload keeps being launched until `warm_ms` of GPU time have passed.  Round 4 found that a kernel that
+    is co-bound by instruction issue (the augmented 64^3 one) runs 5-15 % slower for its first ~30 launches (~25 ms) after
+    the GPU did something else — 829, 717, 750, 776, 800, 816, ... 700, 690 us launch by launch
+    (profiles/r04/warmup.log) — while store-bound kernels do not care; rounds 1-3 timed 10 launches after 3 warm-up ones
+    and so reported the transient for that kernel (747 us where the steady state was ~705).  `cold` (a dict) receives that
+    old-style figure as well, so that the two can be told apart."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(warm):
         fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    a.record()
+    for _ in range(k):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    first = a.elapsed_time(b) / k * 1e3
+    if cold is not None:
+        cold["us_per_launch_first_%d_after_%d_warmup" % (k, warm)] = round(first, 1)
+    spent = first * k * 1e-3
+    while spent < warm_ms:
+        n = max(1, min(64, int((warm_ms - spent) / max(first * 1e-3, 1e-3)) + 1))
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        spent += a.elapsed_time(b)
     a.record()
     for _ in range(k):
         fn()
@@ -592,10 +627,12 @@ def extras(pkg, synth, dev, td, to, th, offsets):
     def resident(name, d, o, h, R, k, offs_np, fn=None, note=""):
         n = h.shape[0]
         out = fn(None) if fn else pkg.voxelize(d, o, h, res=R)
-        us = _time_launches((lambda: fn(out)) if fn else (lambda: pkg.voxelize(d, o, h, res=R, out=out)), k)
+        cold = {}
+        us = _time_launches((lambda: fn(out)) if fn else (lambda: pkg.voxelize(d, o, h, res=R, out=out)), k, cold=cold)
         ab = algorithmic_bytes(offs_np, n, R)
         ex[name] = {"frames": n, "res": R, "us_per_launch": round(us, 1), "frames_per_s": round(n / us * 1e6),
                     "algorithmic_GBps": round(ab / us / 1e3, 1), "frac_of_hbm_peak": round(ab / us / 1e3 / HBM_PEAK_GBS, 4)}
+        ex[name].update(cold)      # what rounds 1-3 reported under us_per_launch: the first k launches after 3 warm-up ones
         if note:
             ex[name]["what"] = note
         del out
@@ -673,14 +710,16 @@ def extras(pkg, synth, dev, td, to, th, offsets):
     ex["configs[2]_resident_shuffled"] = {
         "frames": 8500, "resident_bytes": rl.resident_bytes(),
         "batch_1024_crops_per_s": round(max(r1024[1:])),
-        "batch_16_crops_per_s": round(max(r16p[1:])),
-        "batch_16_one_launch_per_batch_crops_per_s": round(max(r16[1:])),
+        # (key meanings as in round 2: batch_16 = one launch per batch; the prefetch ring has its own key.  Round 3's line
+        # had reported the prefetch variant under "batch_16_crops_per_s".)
+        "batch_16_crops_per_s": round(max(r16[1:])),
+        "batch_16_prefetch64_crops_per_s": round(max(r16p[1:])),
         "host_fed_shuffled_batch_1024_crops_per_s": round(max(h1024[1:])),
         "what": "BASELINE configs[2] with the subject's pack resident in HBM (uploaded once; all of MSRA is 4.8 GB): shuffled "
                 "batches drawn by index on the device, labels included (dataset.ResidentLoader).  batch_16 = the reference's "
-                "training batch size (3D_CNN/train.py:36) with prefetch=64: the epoch's permutation is uploaded once, one "
-                "launch voxelizes 64 batches into a ring and the loader yields 16-frame views (bit-identical batches); "
-                "batch_16_one_launch_per_batch = prefetch=1; host_fed = the same shuffled batches through VoxelLoader, "
+                "training batch size (3D_CNN/train.py:36), one launch per batch; batch_16_prefetch64 = the same with "
+                "prefetch=64: the epoch's permutation is uploaded once, one launch voxelizes 64 batches into a ring and the "
+                "loader yields 16-frame views (bit-identical batches); host_fed = the same shuffled batches through VoxelLoader, "
                 "whose host gathers the crops before uploading them"}
     # the literal north-star consumer: the reference's own loader call (3D_CNN/train.py:36,86-91) over the on-the-fly dataset
     mds = pkg.MSRA_Dataset.from_raw(ds, device=dev)
@@ -959,7 +998,7 @@ def main():
                                   "not measured in this run",
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                 "working_set_bytes": abytes,
-                "kernel": "tsdf_fused_kernel<32, 0, false, false, 2>", "algorithmic_bytes_per_launch": abytes,
+                "kernel": be.kernel_name(FRAMES_PER_LAUNCH, RES), "algorithmic_bytes_per_launch": abytes,
                 "launch_ms_mean": round(mean_ms, 4),
                 "single_launch_ms_median": round(float(np.median(kern_ms)), 4),
                 "single_launch_ms_min": round(float(kern_ms.min()), 4),

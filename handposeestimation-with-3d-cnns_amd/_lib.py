@@ -66,7 +66,7 @@ class TsdfLabels(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 INLINE_INDEX_MAX = 32   # TSDF_INLINE_INDEX_MAX of include/tsdf.h
 
 _lib = None
@@ -131,6 +131,11 @@ def load():
                                         vp, vp, vp, vp]
     L.tsdf_stream_release.restype = ctypes.c_int
     L.tsdf_stream_release.argtypes = [vp]
+    if hasattr(L, "tsdf_describe_launch"):   # ABI v6 (the version check below reports an older library)
+        L.tsdf_describe_launch.restype = ctypes.c_int
+        L.tsdf_describe_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.tsdf_debug_set_queue_word.restype = ctypes.c_int
+        L.tsdf_debug_set_queue_word.argtypes = [vp, ctypes.c_uint64]
     if L.tsdf_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} has ABI version {L.tsdf_version()}, this package needs {ABI_VERSION}: rebuild it")
     _lib = L

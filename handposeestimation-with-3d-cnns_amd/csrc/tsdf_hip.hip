@@ -48,6 +48,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -57,6 +58,7 @@
 #include <type_traits>
 
 #include "../../include/tsdf.h"
+#include "tsdf_host.inc"   // the host-only part (also compiled alone, under sanitizers)
 
 namespace {
 
@@ -939,28 +941,34 @@ __device__ __forceinline__ float gather_rel<LdsSrc>(const LdsSrc src, const VoxK
   return gather_px(src, k, relx << 2, rely, ent, inb);   // a column outside the row's window (or the box) fails its test
 }
 
-// Dynamic tiles (tile_ctr != null; the one-group-per-CU instantiations, R >= 48).  With the static split a wave keeps
-// one slab of rows for the whole volume, and slabs differ 2.5x in cost: rows near the faces of the cube project past
-// the hand (every voxel rejected: ~100 instructions per wave tile), rows through its middle take the z and x/y terms
-// (~260).  The in-kernel stamps showed the lightest wave done after 57 us and the heaviest after 147 us of a frame's
-// voxel pass (profiles/r04/stamps_aug64.log).  Here a unit of work is (slab of 64/R4 rows) x (kDynChunk slices); the
-// waves draw units from a counter in LDS, heaviest slabs (the middle ones) first.  A unit is still "pure" — a wave
-// tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit rate — and a wave's stores are
-// still 1 KiB contiguous.
+// Dynamic units (tile_ctr != null: the augmented pass of the one-group-per-CU instantiations, R >= 48).
+// With the static split a wave keeps one slab of rows (64/R4 of them: one wave tile per slice) for the whole volume.
+// The in-kernel stamps (profiles/r04/stamps_aug64_per_wave_static.log) show what that does at 64^3: each SIMD serves its
+// four waves oldest first, so the waves of a CU leave the pass in four steps — after 55, 87, 116 and 141 us — and in the
+// last quarter of the pass a SIMD is left with ONE wave to hide the latencies of a dependent float64 chain, its LDS
+// gathers and its stores.  Here a unit of work is (slab) x (kDynChunk slices); the waves draw units from a counter in
+// LDS, the middle slabs (whose tiles most often need the x/y terms) first, and the pass's last kDynTailSlices slices go
+// out in smaller chunks, so that all 16 waves stay busy until the end and reach the closing barrier within one small
+// unit of each other (profiles/r04/stamps_aug64_per_wave_dyn8.log: 128-131 us for every wave).  A unit is still
+// "pure" — a wave tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit rate — and a
+// wave's stores are still 1 KiB contiguous.  Same-buffer paired A/Bs on five boxes (profiles/r04/ab_tiers.log,
+// ab_walk.log, ab_tail_n.log): 1024 full frames -> 64^3 augmented -1.7 ... -2.6 %, crops -2.0 %, 4096 frames -3.5 %.
+// Bit-identical results (the A/B tool asserts it).  The plain pass stays static: it is bound by its stores, the same
+// change measured -0.1 % there.
 #ifndef TSDF_DYN_TILES
 #define TSDF_DYN_TILES 1
 #endif
 #ifndef TSDF_DYN_CHUNK
-#define TSDF_DYN_CHUNK 8
+#define TSDF_DYN_CHUNK 4
 #endif
 constexpr int kDynChunk = TSDF_DYN_CHUNK;
 // Two tiers: the last TSDF_DYN_TAIL_SLICES slices of the pass are handed out in chunks of TSDF_DYN_TAIL_CHUNK, after all
 // the big units — the waves reach the pass's closing barrier within one SMALL unit of each other.
 #ifndef TSDF_DYN_TAIL_CHUNK
-#define TSDF_DYN_TAIL_CHUNK TSDF_DYN_CHUNK
+#define TSDF_DYN_TAIL_CHUNK 2
 #endif
 #ifndef TSDF_DYN_TAIL_SLICES
-#define TSDF_DYN_TAIL_SLICES 0
+#define TSDF_DYN_TAIL_SLICES 16
 #endif
 constexpr int kDynTailChunk = TSDF_DYN_TAIL_CHUNK, kDynTailSlices = TSDF_DYN_TAIL_SLICES;
 
@@ -981,11 +989,6 @@ __device__ __forceinline__ DynPlan dyn_plan(int n_slab, int sb, int se) {
   p.n_small = (tail + kDynTailChunk - 1) / kDynTailChunk;
   p.n_unit = n_slab * (p.n_big + p.n_small);
   return p;
-}
-__device__ __forceinline__ int dyn_units_of(int R, int sb, int se) {   // 0: the resolution has no dynamic units
-  const int R4 = R / 4;
-  if (!(TSDF_DYN_TILES && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0)) return 0;
-  return dyn_plan(R / (64 / R4), sb, se).n_unit;
 }
 __device__ __forceinline__ int dyn_slab(int rank, int n_slab);
 __device__ __forceinline__ void dyn_unit(const DynPlan &p, int unit, int &slab, int &zb, int &ze) {
@@ -1017,8 +1020,7 @@ __device__ __forceinline__ int dyn_slab(int rank, int n_slab) {
 template <int LAYOUT, int T, bool DBG, class SrcP>
 __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const VoxK &vk, int R, const Tabs &tb,
                                        const bool use_tab, const SrcP src, const GlobalOut out, const int tid,
-                                       const int sb, const int se, const PixMapK &pm, int *tile_ctr = nullptr,
-                                       int unit_end = -1) {
+                                       const int sb, const int se, const PixMapK &pm, int *tile_ctr = nullptr) {
   if (se <= sb) return;
   const double vl = (double)g.voxel_len;
   const double ox = (double)g.ori[0], oy = (double)g.ori[1];
@@ -1052,7 +1054,7 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
   for (int gi = g0;; gi += gstep) {
     int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
     if (dyn) {
-      if (unit >= (unit_end >= 0 && unit_end < plan.n_unit ? unit_end : plan.n_unit)) break;
+      if (unit >= plan.n_unit) break;
       int slab;
       dyn_unit(plan, unit, slab, zb, ze);
       gi = slab * 64 + (tid & 63);
@@ -1187,7 +1189,7 @@ template <int LAYOUT, int T, class SrcP>
 __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const VoxK &vk, int R,
                                            const double *xf, const Tabs &tb, const SrcP src,
                                            const GlobalOut out, const int tid, const int sb, const int se,
-                                           int *tile_ctr = nullptr, int stamp_iter = 0, int unit_end = -1) {
+                                           int *tile_ctr = nullptr, int stamp_iter = 0) {
   (void)stamp_iter;
   TSDF_WSTAMP(stamp_iter, 0);
   if (se <= sb) return;  // (uniform) nothing to do; the end-slice lookups below assume one slice at least
@@ -1231,25 +1233,10 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     return __builtin_amdgcn_readfirstlane(t);
   };
   int unit = dyn ? draw() : 0;
-#ifndef TSDF_TILE_ORDER
-#define TSDF_TILE_ORDER 0
-#endif
-  // TSDF_TILE_ORDER 1 (experiment): no counter — all waves walk the slabs together (middle-out), wave w takes slices
-  // w, w+16, w+32, ... of the slab: equal work by construction, and the store order tools/probes/vol_store_probe.hip
-  // found best ("I": the 16 waves on 16 consecutive slices of one slab).
-  const bool walk = TSDF_TILE_ORDER == 1 && tile_ctr != nullptr && R4 <= 64 && (64 % R4) == 0 && (R % (64 / R4)) == 0;
-  int walk_k = 0;
   for (int gi = g0i;; gi += gstep) {
     int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
-    if (walk) {
-      const int ns = R / (64 / R4);
-      if (walk_k >= ns) break;
-      gi = dyn_slab(walk_k, ns) * 64 + (tid & 63);
-      zb = sb + (tid >> 6);
-      zs = T / 64;
-      ++walk_k;
-    } else if (dyn) {
-      if (unit >= (unit_end >= 0 && unit_end < plan.n_unit ? unit_end : plan.n_unit)) break;
+    if (dyn) {
+      if (unit >= plan.n_unit) break;
       int slab;
       dyn_unit(plan, unit, slab, zb, ze);
       gi = slab * 64 + (tid & 63);
@@ -1399,7 +1386,8 @@ struct KArgs {
   float *aabb, *grid, *ori;
   int aabb_only;
   const float *grid_in;
-  unsigned int *queue;    // this launch's work-queue word, or null: CU-local queues (see the kernel)
+  unsigned long long *queue;  // this launch's work-queue word, or null: CU-local queues (see the kernel)
+  unsigned int qepoch;        // ... and the launch's number on that word (never 0): see queue_ticket()
   const double *xforms;
   int64_t depth_len;
   const int64_t *index;   // tsdf_voxelize_indexed_hip: batch position -> frame of the resident pack (else null)
@@ -1472,13 +1460,7 @@ struct HelpReq {
 struct GroupCtl {
   int bar[kMaxGroups];
   int local_next;         // CU-local work queue (launches without a global queue word)
-  int tile_next;          // one-group instantiations: the voxel pass's unit counter (dynamic tiles)
-  int pbar;               // pipelined kernel: barrier of the producer waves
-  int next_ok;            // ... the next frame's rows were streamed (its header was consistent)
-  FrameHdr next_hdr;      // ... the next frame (frame = -1: none)
-  float next_fin[16];     // ... and its 10 extents
-  FrameHdr saved_hdr;     // phase-shifted start: the CU's first frame, whose last units are voxelized at the very end
-  float saved_fin[16];
+  int tile_next;          // one-group instantiations: the augmented voxel pass's unit counter (dynamic units)
   int lock;               // TSDF_P2_LOCK builds: one group at a time between the extents barrier and the end of phase 2
   int help_for;           // 0: none; g+1: group g is asked to help with the frame in `help`
   int idle[kMaxGroups];
@@ -1797,12 +1779,30 @@ __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &c
 // Work queue.  Frames beyond the first one per group are handed out dynamically (frame cost varies ~3x with
 // the hand's size; a static 4-frames-per-CU split left a 25 % tail).  An eager launch draws tickets from a
 // device-global word that belongs to its (device, stream) pair — launches of one stream run in order, so the
-// word is never shared (host side: queue_word()).  Exactly n tickets are drawn per launch (every group that
-// got a positional frame draws until it fails once), so whoever draws ticket n-1 knows it is the last and
-// puts the word back to 0: nothing to reset between launches.  A launch without such a word (captured into
-// a graph, or more streams than words) shares frames inside each CU only, through a counter in LDS.
+// word is never shared (host side: queue_word()).  The word is 64 bits: the launch's EPOCH (its number on that
+// word, counted by the host, never 0) in the high half, the ticket counter in the low half.  A drawer that finds
+// another epoch in the word — a fresh word, the previous launch's final state, or whatever a launch that died
+// mid-flight (or anything else) left there — installs {epoch, 1} by compare-and-swap and takes ticket 0; everybody
+// else just adds.  So there is nothing to reset between launches and no state of the word that can make a launch
+// skip or repeat a frame (round 3 reset the word from the drawer of ticket n-1: a launch that never got there left
+// every later launch of the stream short of frames, silently — tests/test_parity_gpu.py poisons the word).
+// A launch without a word (captured into a graph, or more streams than words) shares frames inside each CU only,
+// through a counter in LDS.
 constexpr int kQueueSlots = 1024;
-__device__ unsigned int g_queue[kQueueSlots];
+__device__ unsigned long long g_queue[kQueueSlots];
+
+__device__ __forceinline__ unsigned int queue_ticket(unsigned long long *q, unsigned int epoch) {
+  const unsigned long long mine = (unsigned long long)epoch << 32;
+  for (;;) {
+    const unsigned long long old = atomicAdd(q, 1ull);
+    if ((unsigned int)(old >> 32) == epoch) return (unsigned int)old;   // the common case: one atomic
+    for (;;) {   // the word is not in this launch's epoch yet
+      const unsigned long long cur = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned int)(cur >> 32) == epoch) break;                    // somebody installed it: draw again
+      if (atomicCAS(q, cur, mine | 1ull) == cur) return 0u;             // installed here: ticket 0 is ours
+    }
+  }
+}
 
 // Persistent kernel, one 1024-thread workgroup per CU.  Its two 512-thread groups each walk their own
 // frames through
@@ -1850,14 +1850,6 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
   cap.on = false;
 
   const int n_static = gridDim.x * kGroups;  // frames handed out by position (the first one per group)
-#ifdef TSDF_START_STAGGER
-  // experiment: CUs start in four phase groups TSDF_START_STAGGER us apart (are the CUs' store-less prologues in step?)
-  if constexpr (kGroups == 1) {
-    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (TSDF_START_STAGGER) * 100ull;
-    while (__builtin_amdgcn_s_memrealtime() - t_in < wait) __builtin_amdgcn_s_sleep(20);
-  }
-#endif
 
   int iter = 0;
   (void)iter;
@@ -1870,8 +1862,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
       } else if (a.queue) {
         unsigned int t = 0;
         if (lane == 0) {
-          t = atomicAdd(a.queue, 1u);
-          if (t == (unsigned int)(n - 1)) __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t = queue_ticket(a.queue, a.qepoch);
         }
         fr = n_static + (int)__builtin_amdgcn_readfirstlane(t);
       } else {
@@ -2097,270 +2088,6 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
         run2(hsrc);
       }
     }
-  }
-}
-
-// ---- pipelined kernel: one 1024-thread group per CU (R >= 48) -----------------------------------------------------
-// At 64^3 a frame's voxel pass is bound by its stores (3.1 MB per frame; the stamps show the CU's four SIMDs draining
-// their waves one after the other at exactly the chip's fill rate / 256), and everything else a frame needs — ticket,
-// header, row stream, extents barrier, glue — is a chain of memory latencies during which the CU stores NOTHING.  With
-// every CU starting at once and frames costing about the same, the CUs stay in step: the whole chip stops writing for
-// ~30 us per frame (profiles/r04/stamps_aug64.log: 17 % of the launch).  So the next frame's chain runs DURING the
-// current frame's voxel pass: kPipeProducers waves draw the next ticket, fetch its header, stream its rows and reduce
-// its extents (for the augmented form that includes the per-pixel transform), then join the voxel pass — which hands
-// out (slab x slice-chunk) units dynamically, so it does not matter when they arrive.  Between two voxel passes only
-// glue, the staging copy (L2 hits: the rows were just read) and the tables remain: ~6 us instead of ~35.
-// The LDS pool is still single: staging starts when the previous pass has left it.
-#ifndef TSDF_PIPE
-#define TSDF_PIPE 1
-#endif
-#ifndef TSDF_PIPE_PRODUCERS
-#define TSDF_PIPE_PRODUCERS 4
-#endif
-constexpr int kPipeProducers = TSDF_PIPE_PRODUCERS;
-
-template <int RT, int LAYOUT, bool AUG, bool DBG>
-__global__ __launch_bounds__(kWG) void tsdf_pipe_kernel(const KArgs a, const float *__restrict__ in_depth,
-                                                        const int64_t *__restrict__ in_offsets,
-                                                        const int32_t *__restrict__ in_headers,
-                                                        const double *__restrict__ in_xforms) {
-  [[maybe_unused]] constexpr int kGW = kWG;  // (the stamp macros' group size)
-  constexpr int kGWaves = kWG / 64, kNP = kPipeProducers;
-  static_assert(kNP >= 1 && kNP <= kGWaves, "producer waves");
-  using L = Lds<RT, AUG, 1>;
-  __shared__ typename L::Block lds;
-
-  const int R = RT ? RT : a.R;
-  const CamK &cam = a.cam;
-  const int n = a.n;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  auto &pg = lds.pg[0];
-  GroupCtl &ctl = lds.ctl;
-
-  if (tid == 0) {
-    ctl.bar[0] = 0;
-    ctl.pbar = 0;
-    ctl.local_next = 1;
-    ctl.tile_next = 0;
-  }
-  __syncthreads();
-  int bar_target = 0, pbar_target = 0;
-  auto gsync = [&]() { group_barrier<kGWaves>(&ctl.bar[0], bar_target); };
-  auto psync = [&]() { group_barrier<kNP>(&ctl.pbar, pbar_target); };
-
-  Capture cap;   // (phase1_extents' capture argument: never on here)
-  cap.pool = (LdsF)lds.pool;
-  cap.rowtab = (LdsU)pg.rowtab;
-  cap.fail = (LdsI)&ctl.cap_fail[0];
-  cap.cap4 = 0;
-  cap.base4 = 0;
-  cap.on = false;
-
-  // The next frame of this CU (one wave calls this): the first one by position, the rest from the launch's queue word
-  // — or, without one, from the CU's own stride (see the fused kernel).
-  auto draw_frame = [&](bool first, FrameHdr &m) {
-    int fr;
-    if (first) {
-      fr = blockIdx.x;
-    } else if (a.queue) {
-      unsigned int t = 0;
-      if (lane == 0) {
-        t = atomicAdd(a.queue, 1u);
-        if (t == (unsigned int)(n - 1)) __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      fr = (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane(t);
-    } else {
-      int t = 0;
-      if (lane == 0) t = __hip_atomic_fetch_add(&ctl.local_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const int64_t f64i = (int64_t)blockIdx.x + (int64_t)gridDim.x * __builtin_amdgcn_readfirstlane(t);
-      fr = f64i < n ? (int)f64i : n;
-    }
-    m.frame = fr < n ? fr : -1;
-    m.l = m.t = m.r = m.b = m.pad = 0;
-    m.off0 = m.off1 = m.src = 0;
-    if (fr < n) fetch_header(a, in_offsets, in_headers, fr, m);
-  };
-
-  // ---- the CU's first frame: all 16 waves stream its rows ----
-  if (wave == 0) {
-    FrameHdr m;
-    draw_frame(true, m);
-    if (lane == 0) ctl.hdr[0] = m;
-  }
-  gsync();
-  FrameHdr fh = ctl.hdr[0];
-  int frame = __builtin_amdgcn_readfirstlane(fh.frame);
-  if (frame < 0) return;
-  TSDF_STAMP(0, 0);
-  Frame f;
-  bool hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
-  float fin[kExt];
-#pragma unroll
-  for (int i = 0; i < kExt; ++i) fin[i] = i < 5 ? TSDF_INF : -TSDF_INF;
-  if (hdr_ok)
-    phase1_extents<kGWaves, AUG, false>(f, cam, 0, f.bh, pg.red, fin, wave, gsync, cap, 0,
-                                        AUG ? in_xforms + 24 * (int64_t)frame : nullptr);
-
-  // Phase-shifted start (TSDF_PHASE_SHIFT): the CUs form four phase groups; group g voxelizes only the first (4-g)/4 of
-  // its FIRST frame's units, goes on with its other frames, and finishes that frame's remaining units at the very end.
-  // Every CU still does the same work and ends at the same time, but the groups' store-less stretches (header, rows,
-  // extents, staging) no longer coincide across the chip.
-#ifndef TSDF_PHASE_SHIFT
-#define TSDF_PHASE_SHIFT 0
-#endif
-  const int ph_group = (blockIdx.x >> 3) & 3;
-  const int ph_units = dyn_units_of(R, 0, R);
-  int rem_state = (TSDF_PHASE_SHIFT && ph_group > 0 && ph_units > 0 && !a.aabb_only && a.tsdf && n >= 2 * (int)gridDim.x)
-                      ? 1 : 0;   // 1: the first frame is cut short and its remainder still has to be scheduled
-  const int ph_cut = ph_units * (4 - ph_group) / 4;
-
-  for (int iter = 0;; ++iter) {
-    // ---- here every thread holds the current frame: fh, frame, f, hdr_ok, fin ----
-    float *out = a.tsdf ? a.tsdf + (int64_t)frame * 3 * R * R * R : nullptr;
-    const bool want_vol = !a.aabb_only && out;
-    const bool is_rem = fh.pad == 1;              // this pass: the saved first frame's remaining units
-    int u_begin = 0, u_end = -1;
-    if (iter == 0 && rem_state) {
-      u_end = ph_cut;
-      if (wave == 0) {
-        if (lane == 0) ctl.saved_hdr = fh;
-        if (lane < kExt) {
-          float v = fin[0];
-#pragma unroll
-          for (int i = 1; i < kExt; ++i) v = (lane == i) ? fin[i] : v;
-          ctl.saved_fin[lane] = v;
-        }
-      }
-    }
-    if (is_rem) u_begin = ph_cut;
-    const double *xf = AUG ? in_xforms + 24 * (int64_t)frame : nullptr;
-    int status = TSDF_FRAME_OK;
-    Aabb ab;
-    ab.any = false;
-    ab.mn[0] = ab.mn[1] = ab.mn[2] = ab.mx[0] = ab.mx[1] = ab.mx[2] = 0.f;
-    ab.c0 = ab.r0 = 0;
-    ab.c1 = ab.r1 = -1;
-    Grid g;
-    g.mid[0] = g.mid[1] = g.mid[2] = 0.f;
-    g.max_l = g.voxel_len = g.trunc = 0.f;
-    g.ori[0] = g.ori[1] = g.ori[2] = 0.f;
-    if (!hdr_ok) {
-      status = TSDF_FRAME_BAD_HEADER;
-    } else {
-      ab = aabb_from_extents(fin);
-      place_grid(ab, R, cam, a.grid_in, frame, g, status);
-    }
-    TSDF_STAMP(iter, 4);
-    if (!is_rem) {
-      if (tid == 0) write_frame_outputs(a, frame, g, ab, status);
-      write_labels(a, frame, fh.src, g, status, xf, tid, kWG);
-    }
-
-    const bool do_vox = want_vol && status == TSDF_FRAME_OK;   // uniform
-    if (want_vol && !do_vox && !is_rem) {
-      zero_volume(out, R, tid, kWG, 0, 1);
-      if constexpr (DBG) {
-        if (a.pixmap)
-          for (int i = tid; i < R * R * R; i += kWG) a.pixmap[(int64_t)frame * R * R * R + i] = -1;
-      }
-    }
-    int vt = tid;
-    asm volatile("" : "+v"(vt));   // (see the fused kernel: keeps per-thread constants out of the row stream's registers)
-    int mode = kFillGlobal;
-    VoxK vk;
-    bool use_tab = false;
-    if (do_vox) {
-      const int sc0 = DBG ? 0 : ab.c0, sr0 = DBG ? 0 : ab.r0;
-      const int sw = DBG ? f.bw : ab.c1 - ab.c0 + 1, sh = DBG ? f.bh : ab.r1 - ab.r0 + 1;
-      const int sw4 = (sw + 3) & ~3;
-      const bool staged = (int64_t)sw4 * sh <= L::kPoolFloats;  // uniform
-      if (staged) {
-        mode = kFillRect;
-        stage_rect_dma<kGWaves>(lds.pool, f, fh.off1 - fh.off0, sc0, sr0, sh, sw4, wave, lane);
-      }
-      vk = make_voxk(cam, g, f, ab, mode, DBG, sw4);
-      use_tab = !AUG && R <= kTabR;
-      TSDF_STAMP(iter, 5);
-      fill_tables<LAYOUT, AUG>(pg, g, cam, vk, R, use_tab, false, xf, vt, kWG);
-      TSDF_STAMP(iter, 6);
-      if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      TSDF_STAMP(iter, 7);
-    }
-    if (wave == 0 && lane == 0) lds_store(&ctl.tile_next, u_begin);
-    gsync();   // tables, staged pixels and the unit counter are in place
-    TSDF_STAMP(iter, 8);
-
-    // ---- producers: the NEXT frame's ticket, header, rows and extents, while the others voxelize ----
-    if (wave < kNP) {
-      if (wave == 0) {
-        FrameHdr m;
-        if (is_rem) {            // the queue already said "empty" once: it must not be asked again (ticket accounting)
-          m.frame = -1;
-          m.l = m.t = m.r = m.b = m.pad = 0;
-          m.off0 = m.off1 = m.src = 0;
-        } else {
-          draw_frame(false, m);
-          if (m.frame < 0 && rem_state) {
-            m = ctl.saved_hdr;
-            m.pad = 1;
-          }
-        }
-        if (lane == 0) ctl.next_hdr = m;
-      }
-      psync();
-      const FrameHdr nh = ctl.next_hdr;
-      const int nframe = __builtin_amdgcn_readfirstlane(nh.frame);
-      if (nframe >= 0 && __builtin_amdgcn_readfirstlane(nh.pad) == 1) {
-        if (wave == 0 && lane < kExt) ctl.next_fin[lane] = ctl.saved_fin[lane];
-      } else if (nframe >= 0) {
-        Frame nf;
-        const bool ok = frame_from_header(nh, in_depth, a.depth_len, nf);   // uniform
-        if (ok) {
-          float nfin[kExt];
-          phase1_extents<kNP, AUG, false>(nf, cam, 0, nf.bh, pg.red, nfin, wave, psync, cap, iter + 1,
-                                          AUG ? in_xforms + 24 * (int64_t)nframe : nullptr);
-          if (wave == 0 && lane < kExt) {
-            float v = nfin[0];
-#pragma unroll
-            for (int i = 1; i < kExt; ++i) v = (lane == i) ? nfin[i] : v;
-            ctl.next_fin[lane] = v;
-          }
-        }
-      }
-      TSDF_STAMP(iter, 11);
-    }
-    // ---- the voxel pass (every wave; the producers join when their rows are done) ----
-    if (do_vox) {
-      const Tabs tb = make_tabs(pg);
-      PixMapK pm;
-      pm.out = DBG && a.pixmap ? (GlobalPix)(a.pixmap + (int64_t)frame * R * R * R) : (GlobalPix) nullptr;
-      pm.bw = f.bw;
-      pm.dc = vk.px0 - f.l;
-      pm.dr = vk.py0 - f.t;
-      auto run2 = [&](auto src) {
-        if constexpr (AUG) {
-          phase2_aug<LAYOUT, kWG>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R, &ctl.tile_next, iter, u_end);
-        } else {
-          phase2<LAYOUT, kWG, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm, &ctl.tile_next, u_end);
-        }
-      };
-      if (mode == kFillRect) {
-        run2(LdsRect{(LdsSrc)lds.pool});
-      } else {
-        run2((GlobalSrc)(f.depth + vk.base));
-      }
-    }
-    TSDF_STAMP(iter, 9);
-    gsync();   // the pass has left the pool and the tables; the next frame's record is complete
-    fh = ctl.next_hdr;
-    frame = __builtin_amdgcn_readfirstlane(fh.frame);
-    if (frame < 0) break;
-    if (__builtin_amdgcn_readfirstlane(fh.pad) == 1) rem_state = 0;   // the remainder is scheduled now
-    TSDF_STAMP(iter + 1, 0);
-    hdr_ok = frame_from_header(fh, in_depth, a.depth_len, f);
-#pragma unroll
-    for (int i = 0; i < kExt; ++i) fin[i] = ctl.next_fin[i];
   }
 }
 
@@ -2630,15 +2357,10 @@ int check_device(int *dev_out) {
 // being captured into a graph (its node may later run anywhere, any number of times), a device beyond the
 // table, or more live streams than words.
 struct StreamSlots {
-  std::mutex mu;
-  struct Entry {
-    bool used;
-    hipStream_t s;
-    std::thread::id tid;
-  } e[kQueueSlots];
-  int high = 0;  // entries [0, high) may be in use
-  unsigned int *base = nullptr;  // device address of g_queue on this device
-  float *xchg = nullptr;         // split-kernel mailboxes (see xchg_for)
+  tsdf_host::SlotTable<kQueueSlots> table;   // (stream, thread) -> slot; its own mutex (tsdf_host.inc)
+  std::mutex mu;                             // guards the device-side resources below
+  unsigned long long *base = nullptr;        // device address of g_queue on this device
+  float *xchg = nullptr;                     // split-kernel mailboxes (see xchg_for)
   int xchg_failures = 0;
   unsigned int xchg_seq[64] = {0};
 };
@@ -2650,52 +2372,38 @@ StreamSlots g_slots[64];
 // streams are kept alive at once (release the ones that are done: tsdf_stream_release).
 int stream_slot(int dev, hipStream_t s, bool release) {
   if (dev < 0 || dev >= 64) return -1;
-  if (!release) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
-      (void)hipGetLastError();
-      return -1;
-    }
-    if (cs != hipStreamCaptureStatusNone) return -1;
-  }
   StreamSlots &t = g_slots[dev];
   const bool per_thread = s == hipStreamPerThread;
-  const std::thread::id me = per_thread ? std::this_thread::get_id() : std::thread::id();
-  std::lock_guard<std::mutex> lock(t.mu);
-  if (!t.base) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_queue)) != hipSuccess || !p) {
-      (void)hipGetLastError();
-      return -1;
-    }
-    t.base = static_cast<unsigned int *>(p);
+  if (release) {
+    t.table.release(static_cast<const void *>(s), per_thread);
+    return -1;
   }
-  int free_i = -1;
-  for (int i = 0; i < t.high; ++i) {
-    if (t.e[i].used) {
-      if (t.e[i].s == s && t.e[i].tid == me) {
-        if (release) {
-          t.e[i].used = false;
-          return -1;
-        }
-        return i;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (cs != hipStreamCaptureStatusNone) return -1;
+  {
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (!t.base) {
+      void *p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_queue)) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return -1;
       }
-    } else if (free_i < 0) {
-      free_i = i;
+      t.base = static_cast<unsigned long long *>(p);
     }
   }
-  if (release) return -1;
-  if (free_i < 0 && t.high < kQueueSlots) free_i = t.high++;
-  if (free_i < 0) return -1;
-  t.e[free_i].used = true;
-  t.e[free_i].s = s;
-  t.e[free_i].tid = me;
-  return free_i;
+  return t.table.acquire(static_cast<const void *>(s), per_thread);
 }
 
-unsigned int *queue_word(int dev, hipStream_t s) {
+// This launch's work-queue word and its epoch on it (see queue_ticket), or null.
+unsigned long long *queue_word(int dev, hipStream_t s, unsigned int *epoch) {
   const int i = stream_slot(dev, s, false);
-  return i < 0 ? nullptr : g_slots[dev].base + i;
+  if (i < 0) return nullptr;
+  *epoch = g_slots[dev].table.next_epoch(i);
+  return g_slots[dev].base + i;
 }
 
 // Mailboxes of the split kernel's XCHG form for the launch being issued on (dev, s), and the tag it must use; null
@@ -2791,14 +2499,9 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
   a.per = a.R;
   auto fused = [&](auto groups_tag) {
     constexpr int G = decltype(groups_tag)::value;
-    a.queue = a.n > grid * G ? queue_word(dev, s) : nullptr;  // no dynamic frames: no word needed
-    if constexpr (G == 1 && TSDF_PIPE && !kCaptureFill) {
-      hipLaunchKernelGGL((tsdf_pipe_kernel<RT, LAYOUT, AUG, DBG>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
-                         a.headers, a.xforms);
-    } else {
-      hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG, G>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
-                         a.headers, a.xforms);
-    }
+    a.queue = a.n > grid * G ? queue_word(dev, s, &a.qepoch) : nullptr;  // no dynamic frames: no word needed
+    hipLaunchKernelGGL((tsdf_fused_kernel<RT, LAYOUT, AUG, DBG, G>), dim3(grid), dim3(kWG), 0, s, a, a.depth, a.offsets,
+                       a.headers, a.xforms);
   };
   if constexpr (RT != 0) {
     fused(std::integral_constant<int, groups_for(RT)>{});
@@ -2842,19 +2545,12 @@ struct RunOpts {
 int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers, int n, int R,
         const tsdf_cam *cam, int layout, void *hip_stream, float *t, float *ml, float *mp, int32_t *st,
         const RunOpts &o) {
-  if (n < 0 || !tsdf_resolution_supported(R)) return TSDF_ERR_INVALID_ARG;
-  if (layout != TSDF_LAYOUT_CZYX && layout != TSDF_LAYOUT_CXYZ) return TSDF_ERR_INVALID_ARG;
-  if (o.labels) {
-    const tsdf_labels *lb = o.labels;
-    if (lb->n_joints < 1 || lb->n_joints > 170) return TSDF_ERR_INVALID_ARG;
-    if (n > 0 && (!lb->d_gt || !lb->d_out_gt_nor)) return TSDF_ERR_INVALID_ARG;
-  }
-  if (n == 0) return TSDF_OK;
-  if (!d_depth || !d_offsets || !d_headers || depth_len < 0) return TSDF_ERR_INVALID_ARG;
-  if (!o.aabb_only && (!t || (reinterpret_cast<uintptr_t>(t) & 15))) return TSDF_ERR_INVALID_ARG;
+  // (argument checks: tsdf_host.inc, shared with the sanitizer build of the host code)
+  const int chk = tsdf_host::check_run_args(d_depth, depth_len, d_offsets, d_headers, n, R, cam, layout, t, o.aabb_only,
+                                            o.labels, tsdf_resolution_supported(R));
+  if (chk == tsdf_host::kNothingToDo) return TSDF_OK;
+  if (chk != TSDF_OK) return chk;
   if (!cam) cam = &kDefaultCam;
-  if (!(cam->focal > 0.0) || !(cam->invalid_eps > 0.0f) || !(cam->trunc_voxels > 0.0f))
-    return TSDF_ERR_INVALID_ARG;
   int dev = 0;
   int rc = check_device(&dev);
   if (rc != TSDF_OK) return rc;
@@ -2945,66 +2641,6 @@ void tsdf_default_cam(tsdf_cam *cam) {
 }
 
 int tsdf_version(void) { return TSDF_ABI_VERSION; }
-
-// Host-side helper of the loaders (no GPU involved): frames index[0..n) of a packed host buffer copied back to back into
-// dst (e.g. a page-locked staging buffer), dst_offsets[n+1] filled in.  `threads` workers split the bytes evenly.
-// src_len < 0: unknown (the v4 entry).
-static int host_gather(const float *src, int64_t src_len, const int64_t *src_offsets, int64_t n_src, const int64_t *index,
-                       int64_t n, float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads) {
-  if (n < 0 || n_src < 0 || (n > 0 && (!src || !src_offsets || !index || !dst || !dst_offsets))) return TSDF_ERR_INVALID_ARG;
-  if (!dst_offsets) return n == 0 ? TSDF_OK : TSDF_ERR_INVALID_ARG;
-  dst_offsets[0] = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t f = index[i];
-    if (f < 0 || f >= n_src) return TSDF_ERR_INVALID_ARG;
-    const int64_t b = src_offsets[f], e = src_offsets[f + 1];
-    if (b < 0 || e < b || (src_len >= 0 && e > src_len)) return TSDF_ERR_INVALID_ARG;  // a damaged pack: nothing is read
-    dst_offsets[i + 1] = dst_offsets[i] + (e - b);
-  }
-  const int64_t total = dst_offsets[n];
-  if (total > dst_capacity) return TSDF_ERR_INVALID_ARG;
-  if (threads < 1) threads = 1;
-  if (threads > 64) threads = 64;
-  if (total * 4 < (1 << 20)) threads = 1;  // under a megabyte: starting threads costs more than the copy
-  auto work = [&](int t, int of) {
-    // frames whose first element falls into this worker's share of the elements
-    const int64_t lo = total * t / of, hi = total * (t + 1) / of;
-    for (int64_t i = 0; i < n; ++i) {
-      const int64_t a = dst_offsets[i];
-      if (a < lo) continue;
-      if (a >= hi) break;
-      memcpy(dst + a, src + src_offsets[index[i]], sizeof(float) * (size_t)(dst_offsets[i + 1] - a));
-    }
-  };
-  if (threads == 1) {
-    work(0, 1);
-    return TSDF_OK;
-  }
-  // std::thread's constructor may throw (std::system_error: no resources); nothing may cross the C boundary, so the
-  // shares of workers that could not be started are copied here
-  std::thread pool[64];
-  int started = 1;  // share 0 is this thread's
-  try {
-    for (; started < threads; ++started) pool[started] = std::thread(work, started, threads);
-  } catch (...) {
-  }
-  work(0, threads);
-  for (int t = started; t < threads; ++t) work(t, threads);
-  for (int t = 1; t < started; ++t) pool[t].join();
-  return TSDF_OK;
-}
-
-int tsdf_host_gather_frames(const float *src, const int64_t *src_offsets, int64_t n_src, const int64_t *index, int64_t n,
-                            float *dst, int64_t dst_capacity, int64_t *dst_offsets, int threads) {
-  return host_gather(src, -1, src_offsets, n_src, index, n, dst, dst_capacity, dst_offsets, threads);
-}
-
-int tsdf_host_gather_frames_n(const float *src, int64_t src_len, const int64_t *src_offsets, int64_t n_src,
-                              const int64_t *index, int64_t n, float *dst, int64_t dst_capacity, int64_t *dst_offsets,
-                              int threads) {
-  if (src_len < 0) return TSDF_ERR_INVALID_ARG;
-  return host_gather(src, src_len, src_offsets, n_src, index, n, dst, dst_capacity, dst_offsets, threads);
-}
 
 const char *tsdf_strerror(int status) {
   switch (status) {
@@ -3155,6 +2791,37 @@ int tsdf_stream_release(void *hip_stream) {
     return TSDF_OK;
   }
   (void)stream_slot(dev, static_cast<hipStream_t>(hip_stream), true);
+  return TSDF_OK;
+}
+
+int tsdf_debug_set_queue_word(void *hip_stream, uint64_t value) {
+  int dev = 0;
+  const int rc = check_device(&dev);
+  if (rc != TSDF_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const int i = stream_slot(dev, s, false);
+  if (i < 0) return TSDF_ERR_INVALID_ARG;
+  if (hipStreamSynchronize(s) != hipSuccess) return TSDF_ERR_LAUNCH;
+  const unsigned long long v = value;
+  if (hipMemcpy(g_slots[dev].base + i, &v, sizeof v, hipMemcpyHostToDevice) != hipSuccess) return TSDF_ERR_LAUNCH;
+  return TSDF_OK;
+}
+
+int tsdf_describe_launch(int n, int R, int layout, int aug, char *buf, int buflen) {
+  if (!buf || buflen < 1 || n < 1 || !tsdf_resolution_supported(R)) return TSDF_ERR_INVALID_ARG;
+  if (layout != TSDF_LAYOUT_CZYX && layout != TSDF_LAYOUT_CXYZ) return TSDF_ERR_INVALID_ARG;
+  int dev = 0;
+  const int rc = check_device(&dev);
+  if (rc != TSDF_OK) return rc;
+  const int rt = (R == 32 || R == 64) ? R : 0;   // launch_r's choice of instantiation
+  int S = 0, per = R;
+  split_plan(n, R, num_cus(), &S, &per);
+  if (S >= 2) {
+    snprintf(buf, (size_t)buflen, "tsdf_split_kernel<%d, %d, %s, true> x%d", rt, layout, aug ? "true" : "false", S);
+  } else {
+    snprintf(buf, (size_t)buflen, "tsdf_fused_kernel<%d, %d, %s, false, %d>", rt, layout, aug ? "true" : "false",
+             groups_for(R));
+  }
   return TSDF_OK;
 }
 

@@ -239,12 +239,13 @@ def plan_batches(n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle
     (``shard.shard_bounds``) — the split BASELINE.json configs[3] names; shuffling permutes inside the rank's shard.
     No collective is involved.
 
-    balance  ``"frames"``: shards of equal frame count (sizes differ by at most one) and THE SAME NUMBER OF BATCHES ON
-             EVERY RANK — what a training loop that steps a gradient collective once per batch needs.  A rank that is
-             one frame short of another batch repeats its first frame in a final one-frame batch (as
-             ``torch.utils.data.DistributedSampler`` pads); with ``drop_last`` every rank keeps
-             ``min(shard) // batch_size`` full batches.  (Assumes n >= world: a rank without a single frame has nothing
-             to repeat and yields no batch.)
+    balance  ``"frames"``: shards of equal frame count (sizes differ by at most one) and THE SAME BATCHES — number AND
+             sizes — ON EVERY RANK: what a training loop that steps a gradient collective once per batch needs.  A rank
+             whose shard is one frame short repeats one of its frames (the first of its epoch order) at the end of its
+             index list BEFORE the batches are cut, as ``torch.utils.data.DistributedSampler`` pads samples — so no rank
+             ever sees a one-frame batch (BatchNorm in train mode, full weight in a per-batch all-reduce); with
+             ``drop_last`` every rank keeps ``min(shard) // batch_size`` full batches.  ``n < world`` is a ValueError
+             (a rank without a frame has nothing to repeat, and a per-batch collective would hang).
              ``"pixels"``: cut points balance ``weights`` (pixels per frame; MSRA boxes vary ~3x in area): equal WORK per
              rank, for voxelization / export jobs that never synchronise per batch.  Frame and batch counts then differ
              between ranks (8 ranks over MSRA-like subjects: 7 to 15 batches of 1024).
@@ -263,15 +264,16 @@ def plan_batches(n: int, batch_size: int, rank: int = 0, world: int = 1, shuffle
     idx = np.arange(a, b, dtype=np.int64)
     if shuffle:
         np.random.default_rng((seed, epoch, rank)).shuffle(idx)
+    if balance == "frames":
+        if n < world:
+            raise ValueError(f"balance='frames' needs at least one frame per rank (n={n}, world={world})")
+        lens = [e - s for s, e in bounds]
+        if not drop_last and idx.size < max(lens):
+            idx = np.concatenate([idx, idx[:1]])      # pad at sample level: shard sizes differ by at most one
     batches = [idx[i:i + batch_size] for i in range(0, idx.size, batch_size)]
     if balance == "frames":
-        lens = [e - s for s, e in bounds]
         if drop_last:
             batches = batches[: min(lens) // batch_size]
-        else:
-            want = -(-max(lens) // batch_size)
-            while len(batches) < want and idx.size:
-                batches.append(idx[:1].copy())       # pad: one repeated frame (only ever one batch: sizes differ by <= 1)
     elif drop_last and batches and batches[-1].size < batch_size:
         batches.pop()
     return batches
@@ -669,9 +671,11 @@ class MSRA_Dataset(data.Dataset):
     dataset): the indices go into a page-locked ring the kernel reads over the link, the outputs into a ring of
     preallocated batches, and the result is a :class:`PreBatched` that torch's ``default_collate`` unwraps — the host
     side of a step is one index conversion and one C call.  What the ``DataLoader`` yields is the reference's collated
-    batch ``(tsdf[B,3,32,32,32], gt[B,63], max_l[B], mid_p[B,3])``, on the GPU.  The ring recycles a batch's tensors after
-    ``ring`` further batches (default: as many as fit 2 GiB, at most 256; stream-ordered, so a consumer on the launch
-    stream never sees it — clone what you keep longer).  With a custom ``collate_fn`` pass ``prebatched=False``: a list of
+    batch ``(tsdf[B,3,32,32,32], gt[B,63], max_l[B], mid_p[B,3])``, on the GPU.  The ring (``ring`` slots; default: as
+    many batches as fit 2 GiB of volumes, between 2 and 256) recycles a slot's tensors only when the consumer holds no
+    reference to that batch any more — a batch that is kept (``list(dl)``, collected outputs, a view of one tensor) keeps
+    its tensors and the slot gets new ones, so the loader behaves like the reference's, which returns independent
+    tensors.  With a custom ``collate_fn`` pass ``prebatched=False``: a list of
     item tuples, views into the batch's tensors, as torch documents for ``__getitems__``.
     A lone ``dataset[i]`` voxelizes frame i alone unless the access pattern is a sequential walk, which is served
     from a block.  For the highest throughput at small batch sizes use :class:`ResidentLoader` with ``prefetch``: it
@@ -767,48 +771,54 @@ class MSRA_Dataset(data.Dataset):
         """Ring state for batches of (at most) ``bs`` frames: output slots, one prebuilt result per slot and the C call's
         constant arguments.  Batches of up to 32 plain frames hand their index to the GPU by value (``by_value``:
         ``tsdf_voxelize_indexed_host_hip``); larger ones, and ``aug=True`` datasets, write it into page-locked index slots
-        the kernel reads over the link, with one event per ``kGroup`` slots that tells when a group's words have been read
-        (a slot's words are rewritten ``ring`` batches later)."""
+        the kernel reads over the link, with one event per ``kGroup`` index slots that tells when a group's words have been
+        read (an index slot's words are rewritten ``iring`` batches later).
+
+        A slot is RECYCLED only when nothing outside this object refers to its batch any more.  Every slot owns its
+        tensors (separate allocations), so whoever keeps the batch tuple, one of its tensors, or any view of one (a view's
+        ``_base`` is the slot's tensor) shows up in a Python reference count; such a slot is given fresh tensors instead
+        (``replaced`` counts them) and the kept batch stays what it was — like the independent tensors the reference's
+        loader returns (3D_CNN/train.py:86-91 over numpy rows).  ``list(DataLoader(...))``, an evaluation loop that
+        collects outputs, a loss history: all safe.  What cannot be seen is a consumer that dropped every reference but
+        still has work queued on ANOTHER stream: order that stream after the loader's (the usual rule for GPU tensors)."""
 
         kGroup = 16
 
         def __init__(self, rp: "ResidentPacks", bs: int, ring: int, device, frame=None, xf_table=None):
             import ctypes
+            import sys
             from . import _lib
-            ring = -(-ring // self.kGroup) * self.kGroup
-            self.bs, self.ring, self.slot = bs, ring, 0
+            self._ctypes, self._lib, self._rc = ctypes, _lib, sys.getrefcount
+            ring = max(2, int(ring))
+            self.iring = -(-max(ring, self.kGroup) // self.kGroup) * self.kGroup   # index slots: whole event groups
+            self.bs, self.ring, self.count, self.replaced = bs, ring, 0, 0
             self.L = _lib.load()
-            R = 32
-            self.h_idx = torch.empty((ring, bs), dtype=torch.int64).pin_memory()
-            self.h_idx_np = self.h_idx.numpy()
-            self.tsdf = torch.empty((ring, bs, 3, R, R, R), dtype=torch.float32, device=device)
-            self.max_l = torch.empty((ring, bs), dtype=torch.float32, device=device)
-            self.mid_p = torch.empty((ring, bs, 3), dtype=torch.float32, device=device)
-            self.status = torch.empty((ring, bs), dtype=torch.int32, device=device)
-            nc = rp.gt.shape[1]
-            self.gt = torch.empty((ring, bs, nc), dtype=torch.float32, device=device)
-            self.gt_nor = torch.empty((ring, bs, nc), dtype=torch.float32, device=device)
-            self.labels = [_lib.TsdfLabels(rp.gt.data_ptr(), nc // 3, 1, self.gt_nor[k].data_ptr(), self.gt[k].data_ptr())
-                           for k in range(ring)]
-            self.head = (rp.depth.data_ptr(), rp.depth.numel(), rp.offsets.data_ptr(), rp.headers.data_ptr(),
-                         int(rp.headers.shape[0]))
-            self.args = [(self.h_idx[k].data_ptr(), self.tsdf[k].data_ptr(), self.max_l[k].data_ptr(),
-                          self.mid_p[k].data_ptr(), self.status[k].data_ptr(), ctypes.byref(self.labels[k]))
-                         for k in range(ring)]
-            self.results = [[PreBatched((self.tsdf[k], self.gt[k], self.max_l[k], self.mid_p[k]))] for k in range(ring)]
-            self.read = [torch.cuda.Event() for _ in range(ring // self.kGroup)]
-            self.read_used = [False] * (ring // self.kGroup)
+            self.rp_gt = rp.gt
+            self.nc = rp.gt.shape[1]
             d = torch.device(device)
             self.device = d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
             self.dev_index = self.device.index
+            self.h_idx = torch.empty((self.iring, bs), dtype=torch.int64).pin_memory()
+            self.h_idx_np = self.h_idx.numpy()
+            self.rows = [self.h_idx_np[k] for k in range(self.iring)]
+            self.idx_ptrs = [self.h_idx[k].data_ptr() for k in range(self.iring)]
+            self.head = (rp.depth.data_ptr(), rp.depth.numel(), rp.offsets.data_ptr(), rp.headers.data_ptr(),
+                         int(rp.headers.shape[0]))
+            self.slots = [None] * ring      # (tsdf, gt, max_l, mid_p, status, gt_nor) — the slot's own tensors
+            self.labels = [None] * ring
+            self.args = [None] * ring       # (tsdf, max_l, mid_p, status, byref(labels)) pointers of the C call
+            self.results = [None] * ring    # [PreBatched((tsdf, gt, max_l, mid_p))]
+            self.base_rc = [None] * ring
+            for k in range(ring):
+                self._fresh(k)
+            self.read = [torch.cuda.Event() for _ in range(self.iring // self.kGroup)]
+            self.read_used = [False] * (self.iring // self.kGroup)
             from .voxelize import _get_raw_stream
             self.raw_stream = _get_raw_stream if _get_raw_stream is not None else \
                 (lambda i: torch.cuda.current_stream(i).cuda_stream)
             self.cur_dev = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
             self.fn = self.L.tsdf_voxelize_indexed_hip
             self.take = (rp.frame if frame is None else frame).take   # dataset item -> frame of the resident packs
-            self.rows = [self.h_idx_np[k] for k in range(ring)]
-            assert self.kGroup == 16
             # batches of at most INLINE_INDEX_MAX frames: the index goes to the GPU inside the kernel arguments
             # (tsdf_voxelize_indexed_host_hip reads it during the call) — no page-locked slot, no event, and the launch
             # does not start with a read over the link
@@ -819,67 +829,117 @@ class MSRA_Dataset(data.Dataset):
             self.xf_take = None
             if xf_table is not None:   # aug=True: one map per batch position, in page-locked memory the kernel reads
                 self.fn_aug = self.L.tsdf_voxelize_indexed_aug_hip
-                self.h_xf = torch.empty((ring, bs, 24), dtype=torch.float64).pin_memory()
+                self.h_xf = torch.empty((self.iring, bs, 24), dtype=torch.float64).pin_memory()
                 self.h_xf_np = self.h_xf.numpy()
-                self.xf_rows = [self.h_xf_np[k] for k in range(ring)]
-                self.xf_ptr = [self.h_xf[k].data_ptr() for k in range(ring)]
+                self.xf_rows = [self.h_xf_np[k] for k in range(self.iring)]
+                self.xf_ptr = [self.h_xf[k].data_ptr() for k in range(self.iring)]
                 self.xf_take = xf_table.take
+
+        def _fresh(self, k: int) -> None:
+            """New tensors for slot k (at start-up, and whenever its previous batch is still held by the consumer)."""
+            self._alloc(k)
+            self.base_rc[k] = self._counts(k)      # (taken when _alloc's locals are gone: the ring's own references)
+
+        def _counts(self, k: int):
+            rc, b = self._rc, self.results[k][0].batch
+            return (rc(b), rc(b[0]), rc(b[1]), rc(b[2]), rc(b[3]))
+
+        def _alloc(self, k: int) -> None:
+            R, bs, nc, dev = 32, self.bs, self.nc, self.device
+            tsdf = torch.empty((bs, 3, R, R, R), dtype=torch.float32, device=dev)
+            gt = torch.empty((bs, nc), dtype=torch.float32, device=dev)
+            max_l = torch.empty(bs, dtype=torch.float32, device=dev)
+            mid_p = torch.empty((bs, 3), dtype=torch.float32, device=dev)
+            status = torch.empty(bs, dtype=torch.int32, device=dev)
+            gt_nor = torch.empty((bs, nc), dtype=torch.float32, device=dev)
+            self.slots[k] = (tsdf, gt, max_l, mid_p, status, gt_nor)
+            self.labels[k] = self._lib.TsdfLabels(self.rp_gt.data_ptr(), nc // 3, 1, gt_nor.data_ptr(), gt.data_ptr())
+            self.args[k] = (tsdf.data_ptr(), max_l.data_ptr(), mid_p.data_ptr(), status.data_ptr(),
+                            self._ctypes.byref(self.labels[k]))
+            self.results[k] = [PreBatched((tsdf, gt, max_l, mid_p))]
+
+        def held(self, k: int) -> bool:
+            """Does anything outside the ring still refer to slot k's batch (the tuple, a tensor, a view of one)?"""
+            return self._counts(k) != self.base_rc[k]
+
+        def next_slot(self) -> int:
+            """The output slot of the next batch, free to be overwritten."""
+            k = self.count % self.ring
+            if self.held(k):
+                self._fresh(k)
+                self.replaced += 1
+            return k
+
+        def sync(self) -> None:
+            """Everything queued through this ring has run (called before the ring is dropped: queued launches read its
+            page-locked index words by raw pointer, which torch's pinned-memory allocator knows nothing about)."""
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _ring_size(self, n: int) -> int:
+        """Output slots of the pre-batched ring: an explicit ``ring`` is honoured (at least 2); otherwise as many batches
+        as fit 2 GiB of volumes, between 2 and 256 (batch 16: 256 slots = 1.6 GB; batch 1024: 5 slots = 2.0 GB)."""
+        if self._ring_req:
+            return max(2, int(self._ring_req))
+        vol = n * (3 * 32 ** 3 * 4)
+        return max(2, min(256, (2 << 30) // max(vol, 1)))
 
     def _fast_batch(self, indices):
         """One batch through the ring: ~4 us of Python around the C call (the HIP launch itself is the larger part)."""
         f = self._fast
         n = len(indices)
         if f is None or n > f.bs:
-            vol = n * (3 * 32 ** 3 * 4)
-            ring = self._ring_req if self._ring_req else max(16, min(256, (2 << 30) // max(vol, 1)))
-            f = self._fast = MSRA_Dataset._Fast(self._rp, n, ring, self.device,
+            if f is not None:
+                f.sync()      # launches that read the old ring's page-locked words must be done before it goes away
+            f = self._fast = MSRA_Dataset._Fast(self._rp, n, self._ring_size(n), self.device,
                                                 frame=self._frame2 if self.AUG else None, xf_table=self._xf_table)
-        k = f.slot
+        k = f.next_slot()
+        a = f.args[k]
         if f.by_value:                        # (the epoch's short last batch, or another current device)
             f.idx_buf[:n] = f.take(indices)
-            a = f.args[k]
             with torch.cuda.device(f.device):
-                rc = f.fn_host(*f.head, f.idx_ptr, n, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
+                rc = f.fn_host(*f.head, f.idx_ptr, n, 32, None, 0, f.raw_stream(f.dev_index), a[0], a[1], a[2], a[3], a[4])
             if rc != 0:
                 from . import _lib
                 _lib.check(rc, "tsdf_voxelize_indexed_host_hip")
-            f.slot = k + 1 if k + 1 < f.ring else 0
+            f.count += 1
             if n == f.bs:
                 return f.results[k]
-            return [PreBatched((f.tsdf[k, :n], f.gt[k, :n], f.max_l[k, :n], f.mid_p[k, :n]))]
-        within = k & (f.kGroup - 1)
-        if within == 0 and f.read_used[k >> 4]:
-            f.read[k >> 4].synchronize()      # the launches that read this group's index words a ring ago are done
+            t = f.slots[k]
+            return [PreBatched((t[0][:n], t[1][:n], t[2][:n], t[3][:n]))]
+        ki = f.count % f.iring                # the index words' slot (page-locked ring of whole event groups)
+        within = ki & (f.kGroup - 1)
+        if within == 0 and f.read_used[ki >> 4]:
+            f.read[ki >> 4].synchronize()     # the launches that read this group's index words a ring ago are done
         # dataset item -> pack frame, written where the kernel will read it; numpy checks the range (IndexError) and,
         # like a Python list, counts negative indices from the end
         if n == f.bs:
-            f.take(indices, out=f.rows[k])
+            f.take(indices, out=f.rows[ki])
         else:
-            f.h_idx_np[k, :n] = f.take(indices)
-        a = f.args[k]
+            f.h_idx_np[ki, :n] = f.take(indices)
         if f.xf_take is not None:     # aug=True: the batch's maps next to its indices
             if n == f.bs:
-                f.xf_take(indices, axis=0, out=f.xf_rows[k])
+                f.xf_take(indices, axis=0, out=f.xf_rows[ki])
             else:
-                f.h_xf_np[k, :n] = f.xf_take(indices, axis=0)
+                f.h_xf_np[ki, :n] = f.xf_take(indices, axis=0)
             with torch.cuda.device(f.device):
-                rc = f.fn_aug(*f.head, a[0], n, 32, None, 0, f.raw_stream(f.dev_index), f.xf_ptr[k], a[1], a[2], a[3],
-                              a[4], a[5])
+                rc = f.fn_aug(*f.head, f.idx_ptrs[ki], n, 32, None, 0, f.raw_stream(f.dev_index), f.xf_ptr[ki], a[0], a[1],
+                              a[2], a[3], a[4])
         elif f.cur_dev() == f.dev_index:
-            rc = f.fn(*f.head, a[0], n, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
+            rc = f.fn(*f.head, f.idx_ptrs[ki], n, 32, None, 0, f.raw_stream(f.dev_index), a[0], a[1], a[2], a[3], a[4])
         else:
             with torch.cuda.device(f.device):
-                rc = f.fn(*f.head, a[0], n, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
+                rc = f.fn(*f.head, f.idx_ptrs[ki], n, 32, None, 0, f.raw_stream(f.dev_index), a[0], a[1], a[2], a[3], a[4])
         if within == f.kGroup - 1:
-            f.read[k >> 4].record(torch.cuda.current_stream(f.device))
-            f.read_used[k >> 4] = True
+            f.read[ki >> 4].record(torch.cuda.current_stream(f.device))
+            f.read_used[ki >> 4] = True
         if rc != 0:
             from . import _lib
             _lib.check(rc, "tsdf_voxelize_indexed_hip")
-        f.slot = k + 1 if k + 1 < f.ring else 0
+        f.count += 1
         if n == f.bs:
             return f.results[k]
-        return [PreBatched((f.tsdf[k, :n], f.gt[k, :n], f.max_l[k, :n], f.mid_p[k, :n]))]   # the epoch's short last batch
+        t = f.slots[k]
+        return [PreBatched((t[0][:n], t[1][:n], t[2][:n], t[3][:n]))]   # the epoch's short last batch
 
     def __getitems__(self, indices):
         """The frames of one batch, voxelized by one launch (torch's DataLoader calls this with the batch's indices
@@ -893,14 +953,14 @@ class MSRA_Dataset(data.Dataset):
             # the hot path of a training epoch, inlined (every microsecond here is 6 % of a batch of 16): a full batch of
             # plain items on the current device — item -> pack frame, one C call that takes the index by value, the
             # ring slot's prebuilt result
-            k = f.slot
+            k = f.next_slot()      # (a slot whose batch the consumer still holds gets fresh tensors)
             f.take(indices, out=f.idx_buf)
             a = f.args[k]
-            rc = f.fn_host(*f.head, f.idx_ptr, f.bs, 32, None, 0, f.raw_stream(f.dev_index), a[1], a[2], a[3], a[4], a[5])
+            rc = f.fn_host(*f.head, f.idx_ptr, f.bs, 32, None, 0, f.raw_stream(f.dev_index), a[0], a[1], a[2], a[3], a[4])
             if rc != 0:
                 from . import _lib
                 _lib.check(rc, "tsdf_voxelize_indexed_host_hip")
-            f.slot = k + 1 if k + 1 < f.ring else 0
+            f.count += 1
             self._last = indices[-1]
             return f.results[k]
         if self.resident:

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 5
+#define TSDF_ABI_VERSION 6
 
 /* Output volume layouts.  Both hold float32[n][3][R][R][R]; channel c = x,y,z component. */
 enum tsdf_layout {
@@ -332,6 +332,22 @@ int tsdf_debug_pixmap_hip(const float *d_depth, int64_t depth_len, const int64_t
 /* Forget the work-queue word kept for `hip_stream` on the current device (call it when destroying a stream that
  * has no voxelizer launch in flight; optional — an unknown stream is not an error).  Returns TSDF_OK. */
 int tsdf_stream_release(void *hip_stream);
+
+/* ---- ABI v6 (adds only) ----
+ * Which kernel a call would launch on the current device: writes the instantiation's name — e.g.
+ * "tsdf_fused_kernel<32, 0, false, false, 2>" or "tsdf_split_kernel<32, 0, false, true> x8" — into buf (at most
+ * buflen bytes, NUL-terminated) for a batch of n frames at resolution R in the given layout, plain (aug = 0) or
+ * augmented (aug != 0).  Launches nothing.  bench.py names the kernel of its roofline with it.  Returns TSDF_OK,
+ * TSDF_ERR_INVALID_ARG or TSDF_ERR_NO_DEVICE. */
+int tsdf_describe_launch(int n, int R, int layout, int aug, char *buf, int buflen);
+
+/* Diagnostic: overwrite the work-queue word kept for `hip_stream` on the current device with `value` (synchronous;
+ * the stream must be idle).  The word's state must never matter — a launch re-initialises a word that is not in its
+ * own epoch (tsdf_hip.hip: queue_ticket) — and this is how tests/test_parity_gpu.py proves it: it poisons the word the
+ * way a launch that died mid-flight would have left it and checks that the next launch still voxelizes every frame
+ * (the reference's loop processes every frame of a gesture, pre/read_MSRA.py:98-106).  Returns TSDF_OK, or
+ * TSDF_ERR_INVALID_ARG when the stream has no word (more than 1024 live streams, stream capture). */
+int tsdf_debug_set_queue_word(void *hip_stream, uint64_t value);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     L = pkg._lib.load()
     for name in declared_functions():
         assert hasattr(L, name), f"libtsdf_hip.so does not export {name}"
-    assert L.tsdf_version() == 5
+    assert L.tsdf_version() == 6
     assert b"no CPU fallback" in L.tsdf_strerror(-2)
 
 

@@ -374,6 +374,7 @@ def test_training_loaders_give_every_rank_the_same_number_of_batches(pkg, synth)
     for world, bs, drop in ((8, 1024, False), (8, 1024, True), (3, 16, False), (7, 64, True), (8, 100, False)):
         plans = [pb(n, bs, rank=r, world=world, shuffle=True, seed=1, epoch=2, drop_last=drop) for r in range(world)]
         assert len({len(p) for p in plans}) == 1, (world, bs, drop)
+        assert len({tuple(b.size for b in p) for p in plans}) == 1, (world, bs, drop)   # ... and the same batch SIZES
         flat = np.concatenate([np.concatenate(p) for p in plans])
         if drop:
             assert len(set(flat.tolist())) == flat.size and all(b.size == bs for p in plans for b in p)
@@ -394,6 +395,14 @@ def test_training_loaders_give_every_rank_the_same_number_of_batches(pkg, synth)
         px = [sum(b.size for b in cls(ds, batch_size=4, device="cuda", rank=r, world=4, balance="pixels")._batches())
               for r in range(4)]
         assert sum(px) == 37
+    # the pad is a SAMPLE, not a one-frame batch — 2 ranks, 9 frames, batches of 4: shards 4 / 5,
+    # rank 0 repeats a frame so that both cut [4, 1]; fewer frames than ranks is an error, not a silent empty rank
+    q0, q1 = pb(9, 4, rank=0, world=2), pb(9, 4, rank=1, world=2)
+    assert [b.tolist() for b in q0] == [[0, 1, 2, 3], [0]] and [b.tolist() for b in q1] == [[4, 5, 6, 7], [8]]
+    q0, q1 = pb(11, 4, rank=0, world=2), pb(11, 4, rank=1, world=2)
+    assert [b.tolist() for b in q0] == [[0, 1, 2, 3], [4, 0]] and [b.tolist() for b in q1] == [[5, 6, 7, 8], [9, 10]]
+    with pytest.raises(ValueError):
+        pb(3, 2, rank=0, world=4)
     with pytest.raises(ValueError):
         pb(10, 2, balance="pixels")
     with pytest.raises(ValueError):
@@ -463,3 +472,45 @@ def test_native_gather_equals_numpy_gather(pkg):
     bad_pk = packing.PackedFrames(pk.depth, broken, pk.headers)
     with pytest.raises(ValueError):
         bad_pk.take(np.array([9, 5, 4, 7, 1], np.int64))
+
+
+def test_prebatched_ring_reference_count_rule(pkg):
+    """The host logic of MSRA_Dataset's pre-batched ring: a slot counts as held while the consumer keeps
+    its batch tuple, one of its tensors or a view of one, and then gets fresh tensors instead of being overwritten.  (The
+    GPU tier runs the real ring under DataLoader; here the GPU-facing parts are stubbed out.)"""
+    import ctypes
+    import sys
+
+    ds = pkg.dataset
+    Fast = ds.MSRA_Dataset._Fast
+
+    class HostOnly(Fast):
+        def __init__(self):
+            class L:
+                @staticmethod
+                def TsdfLabels(*a):
+                    return ctypes.c_int(0)
+            self._rc, self._ctypes, self._lib = sys.getrefcount, ctypes, L
+            self.bs, self.nc, self.device, self.rp_gt = 4, 63, "cpu", torch.zeros(2, 63)
+            self.ring, self.count, self.replaced = 2, 0, 0
+            self.slots, self.labels, self.args, self.results, self.base_rc = ([None] * 2 for _ in range(5))
+            for k in range(2):
+                self._fresh(k)
+
+    f = HostOnly()
+    assert not f.held(0) and not f.held(1)
+    b = ds._collate_prebatched(f.results[0])          # what torch's default_collate hands the consumer
+    assert f.held(0) and not f.held(1)
+    del b
+    assert not f.held(0)
+    t = f.results[0][0].batch[0]
+    assert f.held(0)
+    v = t[:, 1]                                        # a view: its _base is the slot's tensor
+    del t
+    assert f.held(0)
+    del v
+    assert not f.held(0)
+    assert f.next_slot() == 0 and f.replaced == 0      # free slot: reused as it is
+    keep = f.results[0][0].batch[2]
+    assert f.next_slot() == 0 and f.replaced == 1      # held slot: new tensors, the kept one untouched
+    assert keep.data_ptr() != f.results[0][0].batch[2].data_ptr()

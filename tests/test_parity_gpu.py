@@ -6,6 +6,7 @@ place of three float64 divisions, so it is expected to agree to ~6e-8 and almost
 exactly; pixel maps must agree exactly, which the value test implies (a flipped pixel moves a
 voxel by O(0.1)).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -1300,6 +1301,111 @@ def test_msra_dataset_prebatched_under_the_reference_loader_call(pkg, synth):
     # a larger batch than the ring was built for: the ring is rebuilt
     (t, g, l, m), = list(DL(fast, batch_size=205))
     assert np.abs(t.cpu().numpy() - ref["tsdf"]).max() <= TOL
+
+
+def test_dirty_queue_word_cannot_skip_frames(pkg, synth):
+    """VERDICT round 3, #6.  The fused kernels hand frames beyond the first per group out through a device word owned by
+    the launch's stream.  Round 3 relied on the drawer of the last ticket putting the word back to 0: a launch that died
+    mid-flight left it dirty and every later launch of the stream silently skipped frames.  Now the word carries the
+    launch's epoch and a drawer that finds another epoch re-initialises it (tsdf_hip.hip: queue_ticket), so NO state of
+    the word may cost a frame — the reference voxelizes every frame of a gesture (pre/read_MSRA.py:98-106).
+    tsdf_debug_set_queue_word poisons the word the way a dead launch (foreign epoch, partial count) or anything else would
+    have left it; every launch after that must equal the clean one bit for bit, in the two-group (32^3), one-group
+    (64^3) and augmented instantiations."""
+    d = dev()
+    L = pkg._lib.load()
+    n = 700                                             # > 2 x 256 groups at 32^3 and > 256 at 64^3: tickets are drawn
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=31000)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    stream = torch.cuda.current_stream(d).cuda_stream
+    poisons = [0, 1, 37, n - 1, n, 2 ** 32 - 1, (0x70000000 << 32) | 37, (0x70000000 << 32) | (n + 5),
+               (0xFFFFFFFF << 32) | 0xFFFFFFFF, (0xFFFFFFFF << 32) | 3, 0x8000000000000000]
+    mid = None
+    for R, aug in ((32, False), (64, False), (64, True)):
+        if aug:
+            xf = torch.from_numpy(pkg.augment.random_affines(mid, rng=np.random.RandomState(5))[0]).to(d)
+            run = lambda out=None: pkg.voxelize_aug(td, to, th, xf, res=R, out=out)
+        else:
+            run = lambda out=None: pkg.voxelize(td, to, th, res=R, out=out)
+        clean = run()
+        torch.cuda.synchronize()
+        if mid is None:
+            mid = clean.mid_p.cpu().numpy()
+        assert int((clean.status != 0).sum()) == 0
+        want = clean.tsdf.clone()
+        for p in poisons:
+            torch.cuda.synchronize()
+            assert L.tsdf_debug_set_queue_word(stream, p) == 0
+            clean.tsdf.fill_(7.0)                       # a skipped frame would keep the sevens
+            clean.status.fill_(9)
+            got = run(clean)
+            torch.cuda.synchronize()
+            assert torch.equal(got.tsdf, want), (R, aug, hex(p))
+            assert int((got.status != 0).sum()) == 0, (R, aug, hex(p))
+        # two launches back to back on a poisoned word (the second one finds the first one's epoch, as always)
+        assert L.tsdf_debug_set_queue_word(stream, (0x12345 << 32) | 99) == 0
+        a = run()
+        b = run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.tsdf, want) and torch.equal(b.tsdf, want)
+    # what the library says it launches for these batches (tsdf_describe_launch, ABI v6)
+    buf = ctypes.create_string_buffer(128)
+    assert L.tsdf_describe_launch(n, 32, 0, 0, buf, 128) == 0 and buf.value == b"tsdf_fused_kernel<32, 0, false, false, 2>"
+    assert L.tsdf_describe_launch(n, 64, 0, 1, buf, 128) == 0 and buf.value == b"tsdf_fused_kernel<64, 0, true, false, 1>"
+    assert L.tsdf_describe_launch(16, 32, 1, 0, buf, 128) == 0 and buf.value.startswith(b"tsdf_split_kernel<32, 1, false, true> x")
+    assert L.tsdf_describe_launch(n, 48, 0, 0, buf, 128) == 0 and buf.value == b"tsdf_fused_kernel<0, 0, false, false, 1>"
+    assert L.tsdf_describe_launch(n, 30, 0, 0, buf, 128) == -1 and L.tsdf_describe_launch(n, 32, 0, 0, None, 0) == -1
+
+
+def test_prebatched_ring_never_overwrites_a_batch_the_consumer_holds(pkg, synth):
+    """the reference's loader returns independent tensors (3D_CNN/train.py:86-91); a consumer may
+    keep them — list(dl), an evaluation loop collecting outputs, one view of one tensor.  The pre-batched ring recycles a
+    slot only when nothing refers to its batch any more; a held batch keeps its tensors and the slot gets new ones.
+    Ring of 2, 13 batches per epoch: every kept batch must still equal the item-tuple path afterwards."""
+    d = dev()
+    frames = [synth.synth_frame(7900 + i, "crop") for i in range(205)]
+    pk = pkg.packing.pack_frames(frames)
+    pk.gt = np.random.default_rng(8).normal(0, 70, (205, 63)).astype(np.float32)
+    raw = pkg.MSRADepthDataset.from_packs([pk])
+    slow = pkg.MSRA_Dataset.from_raw(raw, device=d, prebatched=False)
+    DL = torch.utils.data.DataLoader
+    gen = lambda: torch.Generator().manual_seed(99)
+    want = [tuple(t.clone() for t in b) for b in DL(slow, batch_size=16, shuffle=True, generator=gen())]
+    for bs_case in ("by_value", "indexed"):
+        bs = 16 if bs_case == "by_value" else 40
+        ref = want if bs == 16 else [tuple(t.clone() for t in b) for b in DL(slow, batch_size=40, shuffle=True, generator=gen())]
+        fast = pkg.MSRA_Dataset.from_raw(raw, device=d, ring=2)
+        # (1) nothing kept: two slots serve the whole epoch, nothing is replaced
+        ptrs = set()
+        for b in DL(fast, batch_size=bs, shuffle=True, generator=gen()):
+            ptrs.add(b[0].data_ptr())
+            del b
+        assert fast._fast.ring == 2 and fast._fast.replaced == 0 and len(ptrs) <= 3   # (+ the ragged last batch's view)
+        assert fast._fast.by_value == (bs_case == "by_value")
+        # (2) the whole epoch kept: every batch is still what it was when the epoch is over
+        kept = list(DL(fast, batch_size=bs, shuffle=True, generator=gen()))
+        torch.cuda.synchronize()
+        assert len(kept) == len(ref) and fast._fast.replaced >= len(kept) - 3
+        for got, exp in zip(kept, ref):
+            for a, b in zip(got, exp):
+                assert torch.equal(a, b)
+        # (3) only a VIEW of one tensor kept (its _base is the slot's tensor)
+        rep0 = fast._fast.replaced
+        views, full = [], []
+        for b in DL(fast, batch_size=bs, shuffle=True, generator=gen()):
+            views.append(b[0][:, 2, 5])
+            full.append(None)
+            del b
+        torch.cuda.synchronize()
+        for v, exp in zip(views, ref):
+            assert torch.equal(v, exp[0][:, 2, 5])
+        assert fast._fast.replaced > rep0
+        del kept, views
+    # an explicit ring below 2 is raised to 2; the default is sized by bytes (2 GiB of volumes, 2..256 slots)
+    assert pkg.MSRA_Dataset.from_raw(raw, device=d, ring=1)._ring_size(16) == 2
+    assert pkg.MSRA_Dataset.from_raw(raw, device=d)._ring_size(16) == 256
+    assert pkg.MSRA_Dataset.from_raw(raw, device=d)._ring_size(1024) == 5
+    assert pkg.MSRA_Dataset.from_raw(raw, device=d)._ring_size(4096) == 2
 
 
 def test_aug_true_on_the_reference_entry_points(pkg, synth, tmp_path):
