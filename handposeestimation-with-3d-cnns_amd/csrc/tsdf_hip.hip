@@ -941,70 +941,54 @@ __device__ __forceinline__ float gather_rel<LdsSrc>(const LdsSrc src, const VoxK
   return gather_px(src, k, relx << 2, rely, ent, inb);   // a column outside the row's window (or the box) fails its test
 }
 
-// Dynamic units (tile_ctr != null: the augmented pass of the one-group-per-CU instantiations, R >= 48).
-// With the static split a wave keeps one slab of rows (64/R4 of them: one wave tile per slice) for the whole volume.
-// The in-kernel stamps (profiles/r04/stamps_aug64_per_wave_static.log) show what that does at 64^3: each SIMD serves its
-// four waves oldest first, so the waves of a CU leave the pass in four steps — after 55, 87, 116 and 141 us — and in the
-// last quarter of the pass a SIMD is left with ONE wave to hide the latencies of a dependent float64 chain, its LDS
-// gathers and its stores.  Here a unit of work is (slab) x (kDynChunk slices); the waves draw units from a counter in
-// LDS, the middle slabs (whose tiles most often need the x/y terms) first, and the pass's last kDynTailSlices slices go
-// out in smaller chunks, so that all 16 waves stay busy until the end and reach the closing barrier within one small
-// unit of each other (profiles/r04/stamps_aug64_per_wave_dyn8.log: 128-131 us for every wave).  A unit is still
-// "pure" — a wave tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit rate — and a
-// wave's stores are still 1 KiB contiguous.  Same-buffer paired A/Bs on five boxes (profiles/r04/ab_tiers.log,
-// ab_walk.log, ab_tail_n.log): 1024 full frames -> 64^3 augmented -1.7 ... -2.6 %, crops -2.0 %, 4096 frames -3.5 %.
-// Bit-identical results (the A/B tool asserts it).  The plain pass stays static: it is bound by its stores, the same
-// change measured -0.1 % there.
+// Dynamic units (tile_ctr != null: the one-group-per-CU instantiations, R >= 48).
+// With the static split a wave keeps one slab of rows (64/R4 of them: one wave tile per slice) for the whole volume and
+// walks the slices.  Two things are wrong with that at 64^3 (round 4):
+//  * the ORDER in which the 3 MiB volume is written.  tools/probes/vol_store_probe.hip writes [3][64][64][64] volumes,
+//    store-only, in a dozen orders: the static split's order (its waves in step or out of step) is the slowest of all —
+//    5.0-5.1 TB/s where the best order reaches 6.1 on the same box (profiles/r04/vol_store_probe*.log; on the pool's fast
+//    boxes the spread is 6.5 vs 6.9).  Best: the 16 waves of a CU on consecutive 2-slice pieces of ONE slab, every wave
+//    writing its 1 KiB piece in the three channel planes, then the next slab.  That is what units of (slab) x (2 slices)
+//    drawn from a counter produce.  Paired A/Bs of the real kernels, same buffer (profiles/r04/ab_plain_dyn.log,
+//    ab_aug_chunks.log): plain 64^3 full frames -4.0 %, crops -4.7 %; augmented -3.1 % / -3.2 %.  Units of 1 slice:
+//    -3.6 % / -0.3 %; of 4: +0.2 % / -0.7 %; of 8: +1.4 % (augmented).
+//  * each SIMD serves its four waves oldest first, so a CU's waves leave a static pass in four steps — after 55, 87, 116
+//    and 141 us (profiles/r04/stamps_aug64_per_wave_static.log) — and the youngest wave of each SIMD runs the last
+//    quarter of the pass alone.  With units all 16 waves stay busy to the end (..._dyn8.log: 128-131 us each).
+// A unit is still "pure" — a wave tile's 64 x 4 voxels are neighbours, so the wave-uniform shortcuts keep their hit
+// rate — a wave's stores are still 1 KiB contiguous, and the results are bit-identical (the A/B tool asserts it).  The
+// middle slabs, whose tiles most often need the x/y terms, go first.  Per-slab state of the augmented pass is kept
+// while a wave stays in its slab (it mostly does: a slab's 32 units are drawn one after the other).
+// 32^3 keeps its static two-slices-per-step order: the same probe for 32^3 volumes (vol32_store_probe.hip) finds it
+// among the best already.
 #ifndef TSDF_DYN_TILES
 #define TSDF_DYN_TILES 1
 #endif
 #ifndef TSDF_DYN_CHUNK
-#define TSDF_DYN_CHUNK 4
+#define TSDF_DYN_CHUNK 2
 #endif
 constexpr int kDynChunk = TSDF_DYN_CHUNK;
-// Two tiers: the last TSDF_DYN_TAIL_SLICES slices of the pass are handed out in chunks of TSDF_DYN_TAIL_CHUNK, after all
-// the big units — the waves reach the pass's closing barrier within one SMALL unit of each other.
-#ifndef TSDF_DYN_TAIL_CHUNK
-#define TSDF_DYN_TAIL_CHUNK 2
-#endif
-#ifndef TSDF_DYN_TAIL_SLICES
-#define TSDF_DYN_TAIL_SLICES 16
-#endif
-constexpr int kDynTailChunk = TSDF_DYN_TAIL_CHUNK, kDynTailSlices = TSDF_DYN_TAIL_SLICES;
 
 // The unit plan of one pass over slices [sb, se) with n_slab slabs: unit -> (slab, first slice, end slice).
 struct DynPlan {
-  int n_slab, sb, split, se;       // big chunks cover [sb, split), small ones [split, se)
-  int n_big, n_small, n_unit;      // chunks per slab in each tier; units in all
+  int n_slab, sb, se;
+  int n_chunk, n_unit;      // chunks per slab; units in all
 };
 __device__ __forceinline__ DynPlan dyn_plan(int n_slab, int sb, int se) {
   DynPlan p;
   p.n_slab = n_slab;
   p.sb = sb;
   p.se = se;
-  int tail = kDynTailSlices < se - sb ? kDynTailSlices : 0;
-  if (kDynTailChunk >= kDynChunk) tail = 0;
-  p.split = se - tail;
-  p.n_big = (p.split - sb + kDynChunk - 1) / kDynChunk;
-  p.n_small = (tail + kDynTailChunk - 1) / kDynTailChunk;
-  p.n_unit = n_slab * (p.n_big + p.n_small);
+  p.n_chunk = (se - sb + kDynChunk - 1) / kDynChunk;
+  p.n_unit = n_slab * p.n_chunk;
   return p;
 }
 __device__ __forceinline__ int dyn_slab(int rank, int n_slab);
 __device__ __forceinline__ void dyn_unit(const DynPlan &p, int unit, int &slab, int &zb, int &ze) {
-  const int big_units = p.n_slab * p.n_big;
-  if (unit < big_units) {
-    const int rank = unit / p.n_big, c = unit - rank * p.n_big;
-    slab = dyn_slab(rank, p.n_slab);
-    zb = p.sb + c * kDynChunk;
-    ze = zb + kDynChunk < p.split ? zb + kDynChunk : p.split;
-  } else {
-    const int u = unit - big_units;
-    const int rank = u / p.n_small, c = u - rank * p.n_small;
-    slab = dyn_slab(rank, p.n_slab);
-    zb = p.split + c * kDynTailChunk;
-    ze = zb + kDynTailChunk < p.se ? zb + kDynTailChunk : p.se;
-  }
+  const int rank = unit / p.n_chunk, c = unit - rank * p.n_chunk;
+  slab = dyn_slab(rank, p.n_slab);
+  zb = p.sb + c * kDynChunk;
+  ze = zb + kDynChunk < p.se ? zb + kDynChunk : p.se;
 }
 
 // unit number -> slab: middle-out (n_slab even: h-1, h, h-2, h+1, ...)
@@ -1233,6 +1217,11 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     return __builtin_amdgcn_readfirstlane(t);
   };
   int unit = dyn ? draw() : 0;
+  // Per-slab state, recomputed only when a wave's unit lies in another slab than its previous one (units of one slab are
+  // drawn one after the other, so with small units a wave mostly stays in its slab).
+  int gi_have = -1;
+  double ty0 = 0, ty1 = 0, ty2 = 0, vby = 0, pre[4][3], vbf[4];
+  bool mild = false;
   for (int gi = g0i;; gi += gstep) {
     int zb = sb + s0, ze = se, zs = sstep;   // this pass's slices (uniform)
     if (dyn) {
@@ -1247,42 +1236,46 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
     }
     const int f4i = (gi % R4) * 4;
     const int y = gi / R4;
-    const double ty0 = taby[4 * y], ty1 = taby[4 * y + 1], ty2 = taby[4 * y + 2];
-    const double vby = taby[4 * y + 3];   // v'_y - b_y
-    // The inverse map is (A_i0 x' + A_i1 y') + (A_i2 z' + b_i), every product and sum rounded separately (the
-    // oracle's affine3).  Both brackets depend on grid indices only: the z table holds (A_i2 z' + b_i), and the
-    // bracket that does not change from slice to slice stays in registers — LAYOUT 0 (x, y fixed per lane) keeps
-    // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps the z bracket — so a voxel costs ONE add
-    // per row of the map.  The same goes for v' - b of the distance terms: the fixed axes' live in registers
-    // (vbf), the slice's comes from its table entry.
-    double pre[4][3], vbf[4];
+    if (gi != gi_have) {   // (uniform: every lane of a wave changes slab together)
+      gi_have = gi;
+      ty0 = taby[4 * y];
+      ty1 = taby[4 * y + 1];
+      ty2 = taby[4 * y + 2];
+      vby = taby[4 * y + 3];   // v'_y - b_y
+      // The inverse map is (A_i0 x' + A_i1 y') + (A_i2 z' + b_i), every product and sum rounded separately (the
+      // oracle's affine3).  Both brackets depend on grid indices only: the z table holds (A_i2 z' + b_i), and the
+      // bracket that does not change from slice to slice stays in registers — LAYOUT 0 (x, y fixed per lane) keeps
+      // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps the z bracket — so a voxel costs ONE add
+      // per row of the map.  The same goes for v' - b of the distance terms: the fixed axes' live in registers
+      // (vbf), the slice's comes from its table entry.
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (LAYOUT == 0) {
-        const LdsCD tx = tabx + 4 * (f4i + j);
-        pre[j][0] = tx[0] + ty0;
-        pre[j][1] = tx[1] + ty1;
-        pre[j][2] = tx[2] + ty2;
-        vbf[j] = tx[3];                    // v'_x - b_x
-      } else {
-        const LdsCD tzp = tabz + 4 * (f4i + j);
-        pre[j][0] = tzp[0];
-        pre[j][1] = tzp[1];
-        pre[j][2] = tzp[2];
-        vbf[j] = tzp[3];                   // v'_z - b_z
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (LAYOUT == 0) {
+          const LdsCD tx = tabx + 4 * (f4i + j);
+          pre[j][0] = tx[0] + ty0;
+          pre[j][1] = tx[1] + ty1;
+          pre[j][2] = tx[2] + ty2;
+          vbf[j] = tx[3];                    // v'_x - b_x
+        } else {
+          const LdsCD tzp = tabz + 4 * (f4i + j);
+          pre[j][0] = tzp[0];
+          pre[j][1] = tzp[1];
+          pre[j][2] = tzp[2];
+          vbf[j] = tzp[3];                   // v'_z - b_z
+        }
       }
-    }
-    // Which division (neg_focal_over): v_z of a lane's voxel is fl(pre + slice term), monotone in the slice index
-    // (every rounding is), so its two end slices bound it; same sign and mid-range at both ends -> mid-range throughout.
-    bool mild = mid_range(cam.focal, 0x1p-100, 0x1p100);
-    {
-      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 4 * zb, thi = (LAYOUT == 0 ? tabz : tabx) + 4 * (ze - 1);
+      // Which division (neg_focal_over): v_z of a lane's voxel is fl(pre + slice term), monotone in the slice index
+      // (every rounding is), so the pass's two end slices bound it; same sign and mid-range at both ends -> mid-range
+      // in every slice of every unit of the slab.
+      mild = mid_range(cam.focal, 0x1p-100, 0x1p100);
+      const LdsCD tlo = (LAYOUT == 0 ? tabz : tabx) + 4 * sb, thi = (LAYOUT == 0 ? tabz : tabx) + 4 * (se - 1);
       const double s_lo = LAYOUT == 0 ? tlo[2] : tlo[2] + ty2, s_hi = LAYOUT == 0 ? thi[2] : thi[2] + ty2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const double z_a = pre[j][2] + s_lo, z_b = pre[j][2] + s_hi;
         mild = mild && mid_range(z_a, 0x1p-600, 0x1p600) && mid_range(z_b, 0x1p-600, 0x1p600) && ((z_a > 0.0) == (z_b > 0.0));
       }
+      mild = __all(mild);
     }
     auto slices = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
@@ -1364,7 +1357,7 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
       store_vol4(out + 2 * R3 + e, o2);
     }
     };
-    if (__all(mild)) {
+    if (mild) {
       slices(std::true_type{});
     } else {
       slices(std::false_type{});
@@ -1460,7 +1453,7 @@ struct HelpReq {
 struct GroupCtl {
   int bar[kMaxGroups];
   int local_next;         // CU-local work queue (launches without a global queue word)
-  int tile_next;          // one-group instantiations: the augmented voxel pass's unit counter (dynamic units)
+  int tile_next;          // one-group instantiations: the voxel pass's unit counter (dynamic units)
   int lock;               // TSDF_P2_LOCK builds: one group at a time between the extents barrier and the end of phase 2
   int help_for;           // 0: none; g+1: group g is asked to help with the frame in `help`
   int idle[kMaxGroups];
@@ -1783,25 +1776,55 @@ __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &c
 // word, counted by the host, never 0) in the high half, the ticket counter in the low half.  A drawer that finds
 // another epoch in the word — a fresh word, the previous launch's final state, or whatever a launch that died
 // mid-flight (or anything else) left there — installs {epoch, 1} by compare-and-swap and takes ticket 0; everybody
-// else just adds.  So there is nothing to reset between launches and no state of the word that can make a launch
-// skip or repeat a frame (round 3 reset the word from the drawer of ticket n-1: a launch that never got there left
+// else just adds (two atomics for the first drawers, one for the rest).  In the normal course of things even that does
+// not happen: the drawer of a launch's last ticket leaves the NEXT epoch installed.  So no state of the word can make a
+// launch skip or repeat a frame (round 3 reset the word from the drawer of ticket n-1: a launch that never got there left
 // every later launch of the stream short of frames, silently — tests/test_parity_gpu.py poisons the word).
 // A launch without a word (captured into a graph, or more streams than words) shares frames inside each CU only,
 // through a counter in LDS.
 constexpr int kQueueSlots = 1024;
 __device__ unsigned long long g_queue[kQueueSlots];
 
-__device__ __forceinline__ unsigned int queue_ticket(unsigned long long *q, unsigned int epoch) {
+__device__ __forceinline__ unsigned int queue_next_epoch(unsigned int e) { return e + 1u ? e + 1u : 1u; }  // (host: next_epoch)
+
+__device__ __forceinline__ unsigned int queue_ticket(unsigned long long *q, unsigned int epoch, int n) {
+  // Only read-modify-write atomics read the word.  (A first version re-read it with a plain agent-scope load between
+  // its attempts: the other XCDs' L2s may keep serving such a load a stale line for tens of microseconds — the
+  // compare-and-swap, done at the memory side, then fails against the fresh value again and again.  1024 frames -> 32^3
+  // went from 128 to 179 us that way, bimodally; profiles/r04/ab_queue32.log.  The value a failed compare-and-swap
+  // returns IS the fresh observation.)
   const unsigned long long mine = (unsigned long long)epoch << 32;
+  unsigned int t;
   for (;;) {
     const unsigned long long old = atomicAdd(q, 1ull);
-    if ((unsigned int)(old >> 32) == epoch) return (unsigned int)old;   // the common case: one atomic
-    for (;;) {   // the word is not in this launch's epoch yet
-      const unsigned long long cur = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned int)(cur >> 32) == epoch) break;                    // somebody installed it: draw again
-      if (atomicCAS(q, cur, mine | 1ull) == cur) return 0u;             // installed here: ticket 0 is ours
+    if ((unsigned int)(old >> 32) == epoch) {   // the common case: one atomic
+      t = (unsigned int)old;
+      break;
+    }
+    unsigned long long cur = old + 1;   // the word is not in this launch's epoch; this is what our add left there
+    bool installed = false;
+    for (;;) {
+      const unsigned long long seen = atomicCAS(q, cur, mine | 1ull);
+      if (seen == cur) {
+        installed = true;                                               // installed here: ticket 0 is ours
+        break;
+      }
+      if ((unsigned int)(seen >> 32) == epoch) break;                   // somebody installed it: draw again
+      cur = seen;
+    }
+    if (installed) {
+      t = 0u;
+      break;
     }
   }
+  // Exactly n tickets are drawn per launch (every group that got a positional frame draws until it fails once), so the
+  // drawer of ticket n-1 is the last one to touch the word: it leaves the NEXT launch's epoch installed, and that launch
+  // — the stream's next one, by the host's count — pays one atomic per ticket from its first draw on.  (Without this
+  // every launch started with the install dance: +2.4 % on 1024 full frames -> 32^3, +5 % on crops.)  A launch that
+  // never gets here leaves a foreign epoch behind, which is what the dance is for.
+  if (t == (unsigned int)(n - 1))
+    __hip_atomic_store(q, (unsigned long long)queue_next_epoch(epoch) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return t;
 }
 
 // Persistent kernel, one 1024-thread workgroup per CU.  Its two 512-thread groups each walk their own
@@ -1862,7 +1885,12 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
       } else if (a.queue) {
         unsigned int t = 0;
         if (lane == 0) {
-          t = queue_ticket(a.queue, a.qepoch);
+#ifdef TSDF_QUEUE_OLD
+          t = (unsigned int)atomicAdd(a.queue, 1ull);
+          if (t == (unsigned int)(n - 1)) __hip_atomic_store(a.queue, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+          t = queue_ticket(a.queue, a.qepoch, n);
+#endif
         }
         fr = n_static + (int)__builtin_amdgcn_readfirstlane(t);
       } else {
@@ -2025,7 +2053,8 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
             phase2_aug<LAYOUT, kGW>(g, cam, vk, R, xf, tb, src, (GlobalOut)out, vt, 0, R,
                                     kGroups == 1 ? &ctl.tile_next : nullptr, kGroups * iter + group);
           } else {
-            phase2<LAYOUT, kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm);
+            phase2<LAYOUT, kGW, DBG>(g, cam, vk, R, tb, use_tab, src, (GlobalOut)out, vt, 0, R, pm,
+                                     kGroups == 1 ? &ctl.tile_next : nullptr);
           }
         };
         if (mode == kFillRect) {
@@ -2514,13 +2543,18 @@ hipError_t launch(hipStream_t s, KArgs &a, int dev) {
   return hipGetLastError();
 }
 
-// -DTSDF_DEV_ONLY64 (experiment builds, never the product): only the 64^3 [c,z,y,x] instantiations are compiled —
-// 25 s instead of 3 min per variant; every other call returns hipErrorInvalidValue.
+// -DTSDF_DEV_ONLY64 / -DTSDF_DEV_ONLY32 (experiment builds, never the product): only the 64^3 (32^3) [c,z,y,x]
+// instantiations are compiled — 25 s instead of 3 min per variant; every other call returns hipErrorInvalidValue.
 template <int LAYOUT, bool AUG>
 hipError_t launch_r(hipStream_t s, KArgs &a, int dev) {
-#ifdef TSDF_DEV_ONLY64
+#if defined(TSDF_DEV_ONLY64)
   if constexpr (LAYOUT == 0) {
     if (a.R == 64) return launch<64, LAYOUT, AUG, false>(s, a, dev);
+  }
+  return hipErrorInvalidValue;
+#elif defined(TSDF_DEV_ONLY32)
+  if constexpr (LAYOUT == 0 && !AUG) {
+    if (a.R == 32) return launch<32, LAYOUT, AUG, false>(s, a, dev);
   }
   return hipErrorInvalidValue;
 #else
@@ -2595,11 +2629,11 @@ int run(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const
   a.pixmap = o.pixmap;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipError_t e;
-#ifdef TSDF_DEV_ONLY64
+#if defined(TSDF_DEV_ONLY64) || defined(TSDF_DEV_ONLY32)
   if (o.pixmap) return TSDF_ERR_INVALID_ARG;
 #endif
   if (o.pixmap) {
-#ifndef TSDF_DEV_ONLY64
+#if !defined(TSDF_DEV_ONLY64) && !defined(TSDF_DEV_ONLY32)
     if (layout == TSDF_LAYOUT_CZYX)
       e = R == 32 ? launch<32, 0, false, true>(s, a, dev) : launch<0, 0, false, true>(s, a, dev);
     else

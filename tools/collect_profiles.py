@@ -147,6 +147,20 @@ def summarize2(out):
         s["aug64"] = json.load(open(os.path.join(out, "aug64", "summary.json")))
     except Exception as e:  # noqa: BLE001
         s["aug64"] = str(e)
+    # plain 64^3: whole-run average and steady state (dispatches 41..: see tools/exp_pmc.py)
+    r64 = {}
+    for f in glob.glob(os.path.join(out, "r64_trace", "**", "*_kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "tsdf_fused_kernel<64" in r["Name"]:
+                r64 = {"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                       "min_us": float(r["MinNs"]) / 1e3}
+    for f in glob.glob(os.path.join(out, "r64_trace", "**", "*_kernel_trace.csv"), recursive=True):
+        d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))
+                   if "tsdf_fused_kernel<64" in r["Kernel_Name"])
+        d = [(e - b) / 1e3 for b, e in d]
+        if len(d) > 60 and r64:
+            r64.update({"steady_calls": len(d) - 40, "steady_avg_us": float(np.mean(d[40:])), "first_10_avg_us": float(np.mean(d[:10]))})
+    s["r64"] = r64
     crop = {}
     for f in glob.glob(os.path.join(out, "crop_trace", "**", "*_kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -167,8 +181,35 @@ def summarize2(out):
     print(json.dumps({k: s[k] for k in ("crops_1024",)}, indent=1))
 
 
+def results_table(tag):
+    """DESIGN.md's rocprofv3 column, printed from the TRACKED summary (profiles/<tag>/summary.json) so that the document
+    and the profile cannot disagree:  python3 tools/collect_profiles.py - table r04"""
+    s = json.load(open(os.path.join(ROOT, "profiles", tag, "summary.json")))
+    rows = []
+    kt = s.get("kernel_trace") or {}
+    if kt:
+        rows.append(("1024 full frames -> 32^3 (bench.py under the profiler)", kt["calls"], kt["average_ns"] / 1e3,
+                     kt["min_ns"] / 1e3, None))
+    for key, label in (("r64", "1024 full frames -> 64^3, plain"),):
+        r = s.get(key) or {}
+        if r:
+            rows.append((label, r["calls"], r["avg_us"], r["min_us"], r.get("steady_avg_us")))
+    for kn, r in ((s.get("aug64") or {}).get("kernel_trace") or {}).items():
+        if "<64, 0, true" in kn:
+            rows.append(("1024 full frames -> 64^3, augmented", r["calls"], r["avg_us"], r["min_us"], r.get("steady_avg_us")))
+    c = (s.get("crops_1024") or {}).get("kernel_trace")
+    if c:
+        rows.append(("1024 crops -> 32^3", c["calls"], c["average_ns"] / 1e3, c["min_ns"] / 1e3, None))
+    print("| workload | calls | rocprofv3 average (us) | min (us) | average over dispatches 41.. (us) |")
+    print("|---|---|---|---|---|")
+    for label, calls, avg, mn, steady in rows:
+        print(f"| {label} | {calls} | {avg:.1f} | {mn:.1f} | {'%.1f' % steady if steady else '—'} |")
+
+
 if __name__ == "__main__":
-    if sys.argv[2] == "summarize":
+    if sys.argv[2] == "table":
+        results_table(sys.argv[3])
+    elif sys.argv[2] == "summarize":
         summarize(sys.argv[1])
     elif sys.argv[2] == "summarize2":
         summarize2(sys.argv[1])

@@ -11,8 +11,10 @@ depth, off, hdr = synth.synth_batch(1024, "full", seed0=0)
 td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
 out = pkg.voxelize(td, to, th)
 mode = os.environ.get("PMC_MODE", "aabb")
-K = int(os.environ.get("PMC_LAUNCHES", "30"))   # enough for the trace's AVERAGE to be the steady state (first touch of a
-                                                # fresh 3 GB volume makes the first two launches 10-20 % slower)
+# Launches per run.  Trace runs of the 64^3 kernels take 100: the augmented kernel runs 5-15 % slower for its first ~30
+# launches after the GPU did something else (profiles/r04/warmup.log), so a 30-launch average (rounds 2-3: 739.5 us) is
+# the transient, not the kernel; the summaries report the average over dispatches 41.. as well.  Counter runs keep 30.
+K = int(os.environ.get("PMC_LAUNCHES", "100" if (mode.startswith("aug") or mode == "r64") and os.environ.get("PMC_TRACE") else "30"))
 if mode.startswith("aug"):       # aug32 / aug64: the fused-augmentation kernel (BASELINE configs[4] at aug64)
     R = int(mode[3:] or 64)
     xf = torch.from_numpy(pkg.augment.random_affines(out.mid_p.cpu().numpy(), rng=1)[0]).to(dev)

@@ -30,7 +30,7 @@ python3 tools/collect_profiles.py $OUT summarize
 echo "--- augmented 64^3"
 tools/gpu_pmc_aug.sh profiles_$TAG/aug64 aug64 > $OUT/aug64.log 2>&1 || tail -3 $OUT/aug64.log
 echo "--- plain 64^3"
-PMC_MODE=r64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r64_trace -- python3 tools/exp_pmc.py > $OUT/r64_trace.log 2>&1 || tail -3 $OUT/r64_trace.log
+PMC_TRACE=1 PMC_MODE=r64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r64_trace -- python3 tools/exp_pmc.py > $OUT/r64_trace.log 2>&1 || tail -3 $OUT/r64_trace.log
 echo "--- crops"
 PMC_MODE=crop rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/crop_trace -- python3 tools/exp_pmc.py > $OUT/crop_trace.log 2>&1 || tail -3 $OUT/crop_trace.log
 PMC_MODE=crop rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/crop_fetch -- python3 tools/exp_pmc.py > $OUT/crop_fetch.log 2>&1 || tail -3 $OUT/crop_fetch.log

@@ -1,0 +1,10 @@
+set -e
+O=gpurun_out/r04
+mkdir -p $O
+timeout -k 10 100 tools/probes/vol_store_probe.bin 8 | head -14 | grep -E "^(A|C|D|I|N|K)" >> $O/ab_plain_dyn.log 2>&1
+export AB_AUG=0 AB_SAME_OUT=1 PROF_R=64 AB_BLOCKS=10 AB_LAUNCHES=20
+for v in pl2 pl1 pl4; do
+  python tools/ab_precise.py libtsdf_hip_dev_base.so libtsdf_hip_dev_$v.so >> $O/ab_plain_dyn.log 2>&1
+done
+PROF_KIND=crop python tools/ab_precise.py libtsdf_hip_dev_base.so libtsdf_hip_dev_pl2.so >> $O/ab_plain_dyn.log 2>&1
+grep -v amdgpu.ids $O/ab_plain_dyn.log | tail -20

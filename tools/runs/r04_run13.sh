@@ -1,0 +1,8 @@
+set -e
+O=gpurun_out/r04
+mkdir -p $O
+export AB_SAME_OUT=1 PROF_R=32 AB_BLOCKS=10 AB_LAUNCHES=40
+python tools/ab_precise.py libtsdf_hip_dev32_oldq.so libtsdf_hip_dev32_new.so >> $O/ab_queue32.log 2>&1
+PROF_KIND=crop python tools/ab_precise.py libtsdf_hip_dev32_oldq.so libtsdf_hip_dev32_new.so >> $O/ab_queue32.log 2>&1
+python tools/ab_precise.py libtsdf_hip_r03a.so libtsdf_hip.so >> $O/ab_queue32.log 2>&1
+grep -v amdgpu.ids $O/ab_queue32.log
