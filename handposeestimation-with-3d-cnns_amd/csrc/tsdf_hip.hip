@@ -2133,7 +2133,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
 // The wait is BOUNDED: a workgroup that does not see all mailboxes in time (its siblings are not resident yet,
 // e.g. behind another kernel) streams the whole frame itself, exactly like the non-XCHG form — nothing can
 // deadlock.  The valid-pixel rectangle then comes into LDS by LDS-DMA (its rows were just read by the siblings:
-// L2 hits).  The mailboxes are a lazily allocated per-stream workspace owned by the library (host: xchg_for());
+// L2 hits).  The mailboxes are a per-stream slice of a device global owned by the library (host: xchg_for());
 // launches that cannot have one (stream capture, too many streams) use the redundant form.
 constexpr int kXchgParts = 16;       // mailboxes per frame (upper bound of a.split)
 #ifndef TSDF_XCHG_FRAMES
@@ -2389,8 +2389,7 @@ struct StreamSlots {
   tsdf_host::SlotTable<kQueueSlots> table;   // (stream, thread) -> slot; its own mutex (tsdf_host.inc)
   std::mutex mu;                             // guards the device-side resources below
   unsigned long long *base = nullptr;        // device address of g_queue on this device
-  float *xchg = nullptr;                     // split-kernel mailboxes (see xchg_for)
-  int xchg_failures = 0;
+  float *xchg = nullptr;                     // split-kernel mailboxes: device address of g_xchg (see xchg_for)
   unsigned int xchg_seq[64] = {0};
 };
 StreamSlots g_slots[64];
@@ -2436,29 +2435,23 @@ unsigned long long *queue_word(int dev, hipStream_t s, unsigned int *epoch) {
 }
 
 // Mailboxes of the split kernel's XCHG form for the launch being issued on (dev, s), and the tag it must use; null
-// when the launch cannot have any (stream capture, stream beyond the first kXchgSlots, allocation failed).  The
-// workspace (kXchgSlots x 128 KiB per device) is allocated and zeroed on the first small-batch call on the device —
-// the one time the library allocates; launches of one stream are ordered, so tags only ever grow inside a slot.
+// when the launch cannot have any (stream capture, a stream beyond the first kXchgSlots).  The workspace — kXchgSlots x
+// 128 KiB — is a zero-initialised device global (g_xchg: 8 MiB of the code object's .bss, placed when the library is
+// loaded), so no call ever allocates, clears or synchronises anything (rounds 2-3 allocated it with hipMalloc + hipMemset
+// on the first small-batch call: the one exception to "allocates nothing" the header had to document).  Launches of
+// one stream are ordered, so tags only ever grow inside a slot.
 constexpr int kXchgSlots = 64;
 constexpr size_t kXchgSlotFloats = (size_t)kXchgFrames * kXchgParts * kXchgBox;
+__device__ float g_xchg[kXchgSlots * kXchgSlotFloats];
 float *xchg_for(int dev, hipStream_t s, unsigned int *seq) {
   const int i = stream_slot(dev, s, false);
   if (i < 0 || i >= kXchgSlots) return nullptr;
   StreamSlots &t = g_slots[dev];
   std::lock_guard<std::mutex> lock(t.mu);
   if (!t.xchg) {
-    if (t.xchg_failures >= 8) return nullptr;  // (e.g. another thread's stream capture forbids allocation right now:
-    void *p = nullptr;                          //  try again on a later call, but not forever)
-    const size_t bytes = kXchgSlots * kXchgSlotFloats * sizeof(float);
-    if (hipMalloc(&p, bytes) != hipSuccess) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_xchg)) != hipSuccess || !p) {
       (void)hipGetLastError();
-      ++t.xchg_failures;
-      return nullptr;
-    }
-    if (hipMemset(p, 0, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipFree(p);
-      ++t.xchg_failures;
       return nullptr;
     }
     t.xchg = static_cast<float *>(p);

@@ -15,16 +15,20 @@
  *   - Calls enqueue work on `hip_stream` (a hipStream_t, NULL = default stream)
  *     and return WITHOUT synchronising.  They never print and never throw; they are
  *     re-entrant for distinct streams and may be captured into a hipGraph.  They
- *     allocate nothing — with one exception that happens at most once per device:
- *     the first call with a small batch (n <= CUs/2) outside stream capture allocates
- *     and zeroes an 8 MiB workspace (mailboxes through which the workgroups that share
- *     a frame exchange partial extents; 128 KiB per stream for the first 64 streams),
- *     which synchronises the device that one time.  Captured launches and later
- *     streams never use it.  Work-queue ownership (the kernels hand frames to their
+ *     allocate nothing, clear nothing and never synchronise — the little device state
+ *     the library owns (one work-queue word per stream; 8 MiB of mailboxes through which
+ *     the workgroups that share a frame of a small batch, n <= CUs/2, exchange partial
+ *     extents: 128 KiB per stream for the first 64 streams) is a zero-initialised
+ *     device global placed when the library is loaded.  Captured launches and streams
+ *     beyond the 64th never use the mailboxes.  Work-queue ownership (the kernels hand frames to their
  *     workgroups dynamically): an eager launch uses a device-side queue word owned by
  *     its (device, stream) pair — launches on one stream execute in order, so the word
  *     is never shared, however many launches are in flight; the library keeps one word
- *     per stream it has seen (tsdf_stream_release returns it).  STREAM OWNERSHIP: the word (and the
+ *     per stream it has seen (tsdf_stream_release returns it).  The word carries the number
+ *     of the launch that may draw from it: whatever state an earlier launch left it in — one
+ *     that never finished included — a launch re-initialises a word that is not its own, so
+ *     no state of the word can cost a frame (tsdf_debug_set_queue_word proves it in the tests).
+ *     STREAM OWNERSHIP: the word (and the
  *     mailboxes of small batches) are keyed by the hipStream_t value, so a stream must not be destroyed — and
  *     tsdf_stream_release must not be called for it — while one of its voxelizer launches is still in flight:
  *     hipStreamDestroy returns at once and lets the work drain, and a new stream that is handed the same
