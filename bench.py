@@ -441,6 +441,67 @@ def _time_launches(fn, k, warm=3, warm_ms=40.0, cold=None):
     return a.elapsed_time(b) / k * 1e3
 
 
+def live_traffic(timeout_s=75.0):
+    """HBM bytes per launch of the headline kernel from PMC counters collected BY THIS RUN: three rocprofv3 child passes
+    (FETCH_SIZE of the full entry, WRITE_SIZE of the full entry, FETCH_SIZE of the phase-1-only entry — counters never
+    share a pass with anything but --kernel-trace, FETCH and WRITE need separate passes: MI355X_MICROARCH.md) over
+    tools/exp_pmc.py, which launches the same 1024 seeded frames the timed region uses.  Corrections as the guide
+    prescribes and tools/collect_profiles.py documents: both counters are KiB; FETCH_SIZE reports a wide (16 B/lane)
+    streaming read at 1/2, so the depth stream — isolated by the phase-1-only pass — counts twice; the staging re-read
+    (4 B/lane LDS-DMA, uncalibrated) is priced at its known byte count; WRITE_SIZE is exact.  Returns a dict or None
+    (no rocprofv3, a pass failed or timed out): the caller then falls back to the tracked profiles/pmc_traffic.json and
+    says so.  Children are separate processes (this process has initialised the GPU: it must not exec)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="tsdf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PMC_LAUNCHES="12")
+    kernel = "tsdf_fused_kernel<32, 0, false, false"
+
+    def one(counter, mode):
+        d = os.path.join(tmp, counter + "_" + mode)
+        e = dict(env, PMC_MODE=mode)
+        try:
+            r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                                sys.executable, os.path.join(ROOT, "tools", "exp_pmc.py")],
+                               env=e, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        if r.returncode != 0:
+            return None
+        vals = []
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    vals.append(float(row["Counter_Value"]))
+        return float(np.median(vals)) if vals else None
+
+    try:
+        fetch = one("FETCH_SIZE", "full")
+        write = one("WRITE_SIZE", "full") if fetch is not None else None
+        fetch_p1 = one("FETCH_SIZE", "aabb") if write is not None else None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if fetch is None or write is None or fetch_p1 is None:
+        return None
+    synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
+    stage = 0
+    for i in range(FRAMES_PER_LAUNCH):     # the staged rectangle of every frame: 4 bytes x its bounding rectangle of valid pixels
+        h, d = synth.synth_frame(i, "full")
+        ys, xs = np.nonzero(np.abs(d.reshape(h[5] - h[3], h[4] - h[2])) >= 1)
+        stage += int((ys.max() - ys.min() + 1) * (xs.max() - xs.min() + 1)) * 4
+    wide = fetch_p1 * 1024 * 2
+    return {"hbm_bytes_per_launch": wide + stage + write * 1024, "depth_stream_bytes": wide, "staging_bytes_known": stage,
+            "staging_bytes_reported": (fetch - fetch_p1) * 1024, "write_bytes": write * 1024,
+            "FETCH_SIZE_KiB": fetch, "FETCH_SIZE_KiB_phase1_only": fetch_p1, "WRITE_SIZE_KiB": write}
+
+
 def stream_ceilings():
     """What plain stream kernels reach on THIS box (tools/probes/hbm_probe.hip, built by __graft_entry__.build(); a child
     process, ~2 s): read-only, write-only, copy and the voxelizer's 307:393 read:write mix, best grid of four.  Context
@@ -797,6 +858,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs / latency table (rank 0, N=1)")
     ap.add_argument("--no-config3", action="store_true", help="skip configs[3]_sharded (every rank, every N)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the three rocprofv3 PMC child passes that measure roofline.traffic (rank 0, N=1)")
     args = ap.parse_args()
 
     # stdout carries ONE line, the JSON: everything else that writes to file descriptor 1 during the run — RCCL prints a
@@ -951,10 +1014,24 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate FETCH_SIZE and
         # WRITE_SIZE runs, gfx950 corrections applied; tools/make_profiles.sh writes the file)
         traffic = None
+        traffic_source = None
+        traffic_parts = None
+        under_profiler = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+        if world == 1 and not dry and not rehearsal and not args.no_live_traffic and not under_profiler:
+            del out          # (the children need no memory of ours, but the extras below re-allocate anyway)
+            out = None
+            traffic_parts = live_traffic()
+            if traffic_parts:
+                traffic = traffic_parts["hbm_bytes_per_launch"]
+                traffic_source = ("measured by this run: three rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE, FETCH_SIZE of "
+                                  "the phase-1-only entry) over the same 1024 frames; FETCH x2 for the wide depth stream, the "
+                                  "staging re-read at its known byte count, WRITE exact")
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command from the "
+                                  "tracked profile run, NOT measured in this run (the live passes were skipped or failed)")
             except Exception:
                 traffic = None
         line = {
@@ -994,8 +1071,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command, "
-                                  "not measured in this run",
+                "traffic_source": traffic_source, "traffic_parts": traffic_parts,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                 "working_set_bytes": abytes,
                 "kernel": be.kernel_name(FRAMES_PER_LAUNCH, RES), "algorithmic_bytes_per_launch": abytes,

@@ -1885,12 +1885,7 @@ __global__ __launch_bounds__(kWG) void tsdf_fused_kernel(const KArgs a, const fl
       } else if (a.queue) {
         unsigned int t = 0;
         if (lane == 0) {
-#ifdef TSDF_QUEUE_OLD
-          t = (unsigned int)atomicAdd(a.queue, 1ull);
-          if (t == (unsigned int)(n - 1)) __hip_atomic_store(a.queue, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
           t = queue_ticket(a.queue, a.qepoch, n);
-#endif
         }
         fr = n_static + (int)__builtin_amdgcn_readfirstlane(t);
       } else {

@@ -1545,3 +1545,18 @@ def test_indexed_batches_with_fused_augmentation(pkg, synth):
         ok = b0[4] == 0
         assert bool(ok.any()) and bool(torch.isfinite(b0[0]).all()) and bool(((b0[5] >= 0) & (b0[5] <= 1)).all())
         assert not torch.equal(b0[0], p[0]) and not torch.equal(b0[2], p[2])   # the augmentation did something
+
+
+def test_fuzz_parity_short(pkg):
+    """A short run of tools/fuzz_parity.py inside the suite (the fuzz was "a tool run, not a test"): 40
+    rounds of random geometry / validity / NaNs / batch sizes either side of the split threshold / resolutions / layouts /
+    plain, labelled, indexed and augmented entries / random camera constants against the oracle — status, max_l, mid_p and
+    labels bit for bit, volumes <= 1e-5.  The long runs (up to 1.4 M frames, 0 mismatches) stay in profiles/."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "40", "20261005"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "'bad': 0" in last, last

@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
 # (a step is 16 launches: 6 steps + 1 warm-up + the 50 single launches of the spread pass = 162 launches per pass)
-BENCH="python3 bench.py --steps 6 --warmup 1 --no-extras --no-config3"
+BENCH="python3 bench.py --steps 6 --warmup 1 --no-extras --no-config3 --no-live-traffic"
 python3 bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
 tail -1 $OUT/bench_unprofiled.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
