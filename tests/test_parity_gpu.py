@@ -1560,3 +1560,41 @@ def test_fuzz_parity_short(pkg):
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert "'bad': 0" in last, last
+
+
+@pytest.mark.parametrize("R", [48, 56, 64, 128])
+def test_one_group_kernel_resolutions_against_the_oracle(pkg, synth, R):
+    """The one-group-per-CU instantiations (R >= 48) above the split kernel's batch limit (n > 128): the voxel pass hands
+    out (slab x 2 slices) units dynamically where a slice is a whole number of 64-lane wave tiles (R = 64: 16 slabs of 4
+    rows; R = 128: 64 slabs of 2 rows) and keeps the static split elsewhere (R = 48, 56).  Plain and augmented, both
+    layouts, against the oracle on frames spread over the batch — the first ones (positional), the last ones."""
+    d = dev()
+    n = 132
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=8800 + R)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
+    xf, _ = pkg.augment.random_affines(mid, rng=R)
+    txf = torch.from_numpy(xf).to(d)
+    pick = [0, 1, 63, 130, 131] if R < 128 else [0, 131]
+    sub_off = np.concatenate([[0], np.cumsum([off[i + 1] - off[i] for i in pick])]).astype(np.int64)
+    sub_depth = np.concatenate([depth[off[i]:off[i + 1]] for i in pick])
+    sub_hdr = hdr[pick]
+    for layout in ("czyx", "cxyz"):
+        lay = 0 if layout == "czyx" else 1
+        got = pkg.voxelize(td, to, th, res=R, layout=layout)
+        torch.cuda.synchronize()
+        ref = oracle.voxelize(sub_depth, sub_off, sub_hdr, R=R, layout=lay, n_threads=8)
+        np.testing.assert_array_equal(got.max_l.cpu().numpy()[pick], ref["max_l"])
+        np.testing.assert_array_equal(got.status.cpu().numpy()[pick], ref["status"])
+        assert np.abs(got.tsdf[pick].cpu().numpy() - ref["tsdf"]).max() <= TOL, (R, layout)
+        del got
+        ga = pkg.voxelize_aug(td, to, th, txf, res=R, layout=layout)
+        torch.cuda.synchronize()
+        ra = oracle.voxelize_aug(sub_depth, sub_off, sub_hdr, xf[pick], R=R, layout=lay, n_threads=8)
+        np.testing.assert_array_equal(ga.max_l.cpu().numpy()[pick], ra["max_l"])
+        np.testing.assert_array_equal(ga.mid_p.cpu().numpy()[pick], ra["mid_p"])
+        assert np.abs(ga.tsdf[pick].cpu().numpy() - ra["tsdf"]).max() <= TOL, (R, layout, "aug")
+        del ga
+    buf = ctypes.create_string_buffer(128)
+    assert pkg._lib.load().tsdf_describe_launch(n, R, 0, 0, buf, 128) == 0
+    assert buf.value == (b"tsdf_fused_kernel<%d, 0, false, false, 1>" % (R if R == 64 else 0))
