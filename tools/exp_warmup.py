@@ -48,3 +48,27 @@ for name, fn in (("augmented 64^3", fa), ("plain 64^3", fp)):
     torch.cuda.synchronize()
     t = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(60)]
     print(name, "launch by launch after 1 s idle:", " ".join(f"{x:.0f}" for x in t))
+
+# ---- is the transient the engine clock?  A one-wave probe kernel after every launch reads shader-clock cycles per 100 MHz
+# tick (tools/probes/clk_probe.hip); s_memtime counts at a constant rate on some parts — then the ratio is flat and says so.
+import ctypes
+so = os.path.join(ROOT, "tools", "probes", "libclk_probe.so")
+if os.path.exists(so):
+    C = ctypes.CDLL(so)
+    C.clk_probe_launch.restype = ctypes.c_int
+    C.clk_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    N = 60
+    buf = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, fn in (("augmented 64^3", fa), ("plain 64^3", fp)):
+        torch.cuda.synchronize(); time.sleep(1.0)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * N)]
+        for i in range(N):
+            ev[2 * i].record(); fn(); ev[2 * i + 1].record()
+            C.clk_probe_launch(stream, buf[i].data_ptr(), 20000)
+        torch.cuda.synchronize()
+        t = [ev[2 * i].elapsed_time(ev[2 * i + 1]) * 1e3 for i in range(N)]
+        b = buf.cpu().numpy()
+        mhz = b[:, 0] / np.maximum(b[:, 1], 1) * 100.0
+        print(name, "launch us :", " ".join(f"{x:.0f}" for x in t))
+        print(name, "probe MHz :", " ".join(f"{x:.0f}" for x in mhz))
