@@ -441,7 +441,7 @@ def _time_launches(fn, k, warm=3, warm_ms=40.0, cold=None):
     return a.elapsed_time(b) / k * 1e3
 
 
-def live_traffic(timeout_s=75.0):
+def live_traffic(timeout_s=45.0):
     """HBM bytes per launch of the headline kernel from PMC counters collected BY THIS RUN: three rocprofv3 child passes
     (FETCH_SIZE of the full entry, WRITE_SIZE of the full entry, FETCH_SIZE of the phase-1-only entry — counters never
     share a pass with anything but --kernel-trace, FETCH and WRITE need separate passes: MI355X_MICROARCH.md) over
