@@ -790,7 +790,8 @@ def test_pixel_map_exact_on_a_batch(pkg, synth):
     """The same exact comparison over seeded batches (work queue, tail help, global-gather fallback for the full
     frames whose bounding box does not fit the LDS pool) and a resolution without projection tables."""
     d = dev()
-    for kind, n, R in (("crop", 600, 32), ("full", 40, 32), ("crop", 12, 48)):
+    # (round 4: R = 64 goes through the one-group kernel's dynamic (slab x 2 slices) units, both gather sources)
+    for kind, n, R in (("crop", 600, 32), ("full", 40, 32), ("crop", 12, 48), ("crop", 20, 64), ("full", 6, 64)):
         depth, off, hdr = synth.synth_batch(n, kind, seed0=5100)
         ref = oracle.voxelize(depth, off, hdr, R=R, n_threads=8, extras=True)
         t, pm, st = pkg.voxel_pixels(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d),
