@@ -1599,3 +1599,40 @@ def test_one_group_kernel_resolutions_against_the_oracle(pkg, synth, R):
     buf = ctypes.create_string_buffer(128)
     assert pkg._lib.load().tsdf_describe_launch(n, R, 0, 0, buf, 128) == 0
     assert buf.value == (b"tsdf_fused_kernel<%d, 0, false, false, 1>" % (R if R == 64 else 0))
+
+
+def test_one_group_kernels_captured_into_a_graph(pkg, synth):
+    """The one-group (64^3) kernels under stream capture: no queue word (frames dealt by a counter in LDS), the voxel
+    pass's dynamic units as ever (their counter lives in LDS too).  A captured plain launch and a captured augmented
+    launch, replayed twice each — once concurrently on two streams — equal the eager results bit for bit."""
+    d = dev()
+    n = 300
+    depth, off, hdr = synth.synth_batch(n, "crop", seed0=9900)
+    td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
+    mid = pkg.voxelize(td, to, th).mid_p.cpu().numpy()
+    txf = torch.from_numpy(pkg.augment.random_affines(mid, rng=3)[0]).to(d)
+    ref_p = pkg.voxelize(td, to, th, res=64)
+    ref_a = pkg.voxelize_aug(td, to, th, txf, res=64)
+    out_p = pkg.voxelize(td, to, th, res=64)
+    out_a = pkg.voxelize_aug(td, to, th, txf, res=64)
+    torch.cuda.synchronize()
+    cs = torch.cuda.Stream(d)
+    gp, ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cs):
+        with torch.cuda.graph(gp, stream=cs):
+            pkg.voxelize(td, to, th, res=64, out=out_p)
+        with torch.cuda.graph(ga, stream=cs):
+            pkg.voxelize_aug(td, to, th, txf, res=64, out=out_a)
+    s1, s2 = torch.cuda.Stream(d), torch.cuda.Stream(d)
+    for rnd in range(3):
+        out_p.tsdf.zero_()
+        out_a.tsdf.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            gp.replay()
+        with torch.cuda.stream(s2):
+            ga.replay()
+            gp.replay()                     # the plain graph concurrently with itself (same outputs, same values)
+        torch.cuda.synchronize()
+        assert torch.equal(out_p.tsdf, ref_p.tsdf) and torch.equal(out_p.max_l, ref_p.max_l), rnd
+        assert torch.equal(out_a.tsdf, ref_a.tsdf) and torch.equal(out_a.mid_p, ref_a.mid_p), rnd
