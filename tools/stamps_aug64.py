@@ -122,3 +122,15 @@ for rep in range(int(os.environ.get("STAMPS_REPS", "2"))):
         span = endrel.max(axis=1)
         print(f"      pass length (last wave out) median {np.median(span):.1f} us; first wave out median {np.median(endrel.min(axis=1)):.1f} us; "
               f"mean wave busy {100 * np.mean(dur.sum(axis=1) / (16 * span)):.0f} % of the pass")
+    # ---- who ends last?  per XCD (workgroups go to the 8 XCDs round robin by blockIdx) and the latest CUs' frames
+    endus = end / 100.0
+    print("   CU end percentiles p50/p75/p90/p95/p99/max: " + " ".join(f"{x:7.1f}" for x in np.percentile(endus, [50, 75, 90, 95, 99, 100])))
+    print("   mean CU end per XCD (blockIdx % 8): " + " ".join(f"{endus[x::8].mean():7.1f}" for x in range(8)))
+    late = np.argsort(endus)[-8:][::-1]
+    for cu in late:
+        durs = [(s[cu, it, 9] - (s[cu, it - 1, 9] if it else t0)) / 100.0 for it in range(int(cnt[cu]))]
+        print(f"      CU {cu:3d} (XCD {cu % 8}) ends {endus[cu]:7.1f}: frame spans " + " ".join(f"{x:6.1f}" for x in durs))
+    early = np.argsort(endus)[:4]
+    for cu in early:
+        durs = [(s[cu, it, 9] - (s[cu, it - 1, 9] if it else t0)) / 100.0 for it in range(int(cnt[cu]))]
+        print(f"      CU {cu:3d} (XCD {cu % 8}) ends {endus[cu]:7.1f}: frame spans " + " ".join(f"{x:6.1f}" for x in durs))
