@@ -46,6 +46,9 @@ for rep in range(3):
     print(f"rep {rep}: {N} {kind} frames; frames/group histogram: "
           + ", ".join(f"{k}:{int((cnt == k).sum())}" for k in range(cnt.max() + 1))
           + f"  (stamps keep {FR // G} frames per group)")
+    cu_end = endus.max(axis=1)
+    print("   mean CU end per XCD (blockIdx % 8): " + " ".join(f"{cu_end[x::8].mean():7.1f}" for x in range(8))
+          + f"   (all CUs: mean {cu_end.mean():.1f}, max {cu_end.max():.1f})")
     q = np.percentile(endus, [0, 10, 50, 90, 99, 100])
     print("   group end (us) min/p10/p50/p90/p99/max: " + " ".join(f"{x:7.2f}" for x in q))
     hv = s[:, :, 10]
