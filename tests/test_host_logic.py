@@ -514,3 +514,24 @@ def test_prebatched_ring_reference_count_rule(pkg):
     keep = f.results[0][0].batch[2]
     assert f.next_slot() == 0 and f.replaced == 1      # held slot: new tensors, the kept one untouched
     assert keep.data_ptr() != f.results[0][0].batch[2].data_ptr()
+
+
+def test_design_quotes_the_tracked_rocprof_numbers():
+    """"docs and tracked profiles disagree by 3 %".  DESIGN.md's rocprofv3 column must be what
+    tools/collect_profiles.py prints from the TRACKED profiles/r04/summary.json: every average / minimum / steady-state
+    figure of that table appears in DESIGN.md literally."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "collect_profiles.py"), "-", "table", "r04"],
+                       capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("| ") and "workload" not in ln and "---" not in ln]
+    assert len(rows) >= 4
+    for ln in rows:
+        cells = [c.strip() for c in ln.strip("|").split("|")]
+        for num in cells[2:]:
+            if re.fullmatch(r"\d+\.\d", num):
+                assert num in design, f"DESIGN.md does not quote {num} ({cells[0]})"
