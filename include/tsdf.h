@@ -189,8 +189,8 @@ int tsdf_voxelize_grid_hip(const float *d_depth, int64_t depth_len, const int64_
  *   grid is mapped back (T^-1 with separately rounded products and sums grouped as (A_i0 x + A_i1 y) +
  *   (A_i2 z + b_i)), projected and gathered as in tsdf_voxelize_hip, and the truncated distances are those
  *   between v' and T(w), w the surface point of the gathered pixel.  ABI v5 states them in the cheapest exact
- *   form an affine T allows (the kernel is VALU-bound; v4 formed w and T(w) explicitly, about twice the float64
- *   work per voxel): with dxi = pix_x - cx, dyi = pix_y - cy, iF = 1/F, it = 1/trunc_dis, float64, one rounding
+ *   form an affine T allows (v4 formed w and T(w) explicitly, about twice the float64 work per voxel, when round 2
+ *   had measured the kernel bound by instruction issue; since round 4 it is ~9/10 memory system): with dxi = pix_x - cx, dyi = pix_y - cy, iF = 1/F, it = 1/trunc_dis, float64, one rounding
  *   per operation,
  *       g_i0 = -(A_i0 * iF),  g_i1 = A_i1 * iF                          per frame
  *       c_i  = fma(g_i0, dxi, fma(g_i1, dyi, A_i2))
