@@ -50,7 +50,8 @@ sys.path.insert(0, ROOT)
 
 FRAMES_PER_LAUNCH = 1024
 LAUNCHES_PER_STEP = 16
-FRAMES_PER_GPU = FRAMES_PER_LAUNCH          # (name kept: frames resident per GPU = one launch's batch)
+FRAMES_PER_GPU = FRAMES_PER_LAUNCH          # (name kept: frames per GPU and launch)
+ROTATION = 6                                # distinct resident batches (+ output buffers) a rank's launches rotate through
 RES = 32
 ALL_SUBJECTS = 76500   # BASELINE configs[3]: all nine MSRA subjects
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
@@ -208,13 +209,78 @@ except AttributeError:   # pragma: no cover
     _ALLOWED_AT_START = frozenset()
 
 
-def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5, all_s=2.5):
-    """Time the oracle on host cores over the same frames, as BASELINE.md section 4 / SURVEY.md 8(d) ask: ONE thread and ALL
-    the cores the process is allowed (the count printed), plus the 16-thread figure earlier rounds reported (a one-GPU
-    box's nominal CPU share).  Whole passes over the 1024-frame batch are repeated until a leg's budget is used, so the
-    sample is always a multiple of the bench workload; about 4 + 1.5 x 16 + 2.5 x allowed seconds of CPU work.  The rank
-    pinned itself to its GPU's NUMA node at start-up: for this measurement the mask the process STARTED with is put back
-    (OpenMP workers inherit the mask of the thread that creates them) and the pinned one restored afterwards."""
+def cgroup_cpu_quota(root: str = "/sys/fs/cgroup", proc_cgroup: str = "/proc/self/cgroup"):
+    """CPUs' worth of run time the cgroup CPU controller grants this process: quota / period of the tightest limit on the
+    path from the process's cgroup up to the root (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us` / `cpu.cfs_period_us`).
+    Returns (cpus as a float or None when unlimited or unreadable, where it was read)."""
+    paths = {}
+    try:
+        for ln in open(proc_cgroup):
+            _, ctrl, path = ln.rstrip("\n").split(":", 2)
+            paths[ctrl] = path
+    except (OSError, ValueError):
+        pass
+    best, where, seen = None, "no cgroup CPU controller file readable", []
+
+    def walk(base, rel):
+        parts = [p for p in rel.split("/") if p]
+        for k in range(len(parts), -1, -1):
+            yield os.path.join(base, *parts[:k])
+
+    # v2 (unified hierarchy, either at the root or under "unified")
+    for base in (root, os.path.join(root, "unified")):
+        for d in walk(base, paths.get("", "/")):
+            try:
+                q, per = open(os.path.join(d, "cpu.max")).read().split()[:2]
+            except (OSError, ValueError):
+                continue
+            seen.append(os.path.join(d, "cpu.max"))
+            if q != "max" and float(per) > 0 and (best is None or float(q) / float(per) < best):
+                best, where = float(q) / float(per), os.path.join(d, "cpu.max")
+    # v1
+    rel = next((v for k, v in paths.items() if "cpu" in k.split(",")), "/")
+    for base in (os.path.join(root, "cpu"), os.path.join(root, "cpu,cpuacct")):
+        for d in walk(base, rel):
+            try:
+                q = float(open(os.path.join(d, "cpu.cfs_quota_us")).read())
+                per = float(open(os.path.join(d, "cpu.cfs_period_us")).read())
+            except (OSError, ValueError):
+                continue
+            seen.append(os.path.join(d, "cpu.cfs_quota_us"))
+            if q > 0 and per > 0 and (best is None or q / per < best):
+                best, where = q / per, os.path.join(d, "cpu.cfs_quota_us")
+    if best is None and seen:
+        where = "no limit set in " + ", ".join(seen)
+    return best, where
+
+
+def plan_cpu_legs(n_allowed: int, quota):
+    """Thread counts the CPU baseline times, and the one the box is believed to be able to run in parallel.  1 thread
+    always; the quota's count when the cgroup states one (never more than the affinity mask allows); with no quota the
+    affinity count — and, when that is above 16, 16 as well: a one-GPU box of the pool shows all 256 CPUs of its host in
+    the mask and no cgroup quota, while its real share is 16 (256 OpenMP threads then run 5x SLOWER than 16: round 4)."""
+    if quota is not None:
+        usable = max(1, min(n_allowed, int(quota + 0.999)))
+        why = "cgroup quota"
+    else:
+        usable = max(1, n_allowed)
+        why = "affinity mask (no cgroup quota)"
+    legs = [1]
+    if quota is None and n_allowed > 16:
+        legs.append(16)
+    if usable not in legs:
+        legs.append(usable)
+    return legs, usable, why
+
+
+def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=2.0, legs_override=None):
+    """Time the oracle on host cores over the same frames (BASELINE.md section 4 / SURVEY.md 8(d)): one thread, and the
+    number of threads the box can really run — the cgroup CPU quota when there is one, else the affinity mask (plus a
+    16-thread leg when that mask is wider than 16: see plan_cpu_legs).  `value` / `cores` are the FASTEST leg; every leg
+    is listed with its thread count.  Whole passes over the 1024-frame batch are repeated until a leg's budget is used, so
+    the sample is always a multiple of the bench workload.  The rank pinned itself to its GPU's NUMA node at start-up: for
+    this measurement the mask the process STARTED with is put back (OpenMP workers inherit the mask of the thread that
+    creates them) and the pinned one restored afterwards."""
     import oracle  # test infrastructure; used here only as the reported CPU baseline
 
     oracle.lib()  # build/load outside the timed region
@@ -227,6 +293,10 @@ def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5, all_s=2.5):
     except (AttributeError, OSError):
         pinned = None
     n_all = len(allowed)
+    quota, quota_where = cgroup_cpu_quota()
+    legs, usable, why = plan_cpu_legs(n_all, quota)
+    if legs_override:
+        legs = list(legs_override)
 
     def leg(nthreads, budget):
         oracle.voxelize(depth[: offsets[16]], offsets[:17], headers[:16], R=RES, n_threads=nthreads)  # warm
@@ -237,26 +307,28 @@ def cpu_baseline(depth, offsets, headers, single_s=4.0, multi_s=1.5, all_s=2.5):
             used = r["threads"]
             dt = time.perf_counter() - t0
             if dt >= budget:
-                return frames / dt, frames, dt, used
+                return {"threads": int(used), "frames_per_s": round(frames / dt, 1), "frames": frames, "seconds": round(dt, 2)}
 
     try:
-        fps1, n1, t1, _ = leg(1, single_s)
-        fps16, n16, t16, used16 = leg(min(16, n_all), multi_s)
-        fpsN, nN, tN, used = (fps16, n16, t16, used16) if n_all <= 16 else leg(n_all, all_s)
+        done = [leg(t, single_s if t == 1 else multi_s) for t in legs]
     finally:
         if pinned is not None:
             try:
                 os.sched_setaffinity(0, pinned)
             except OSError:
                 pass
+    best = max(done, key=lambda r: r["frames_per_s"])
+    single = done[0]
     return {
-        "value": round(fpsN, 1), "unit": "frames/s", "cores": int(used), "kind": "port",
+        "value": best["frames_per_s"], "unit": "frames/s", "cores": best["threads"], "kind": "port",
         "sample": f"oracle/tsdf_oracle.c (C restatement of the reference math; the numba path itself is not "
-                  f"runnable: no usable numba, no params.py) over the same 1024 synthetic frames: "
-                  f"{nN} frames in {tN:.2f} s on {used} OpenMP threads (= every CPU the process is allowed); "
-                  f"{n16} frames in {t16:.2f} s on {used16} threads; single thread {n1} frames in {t1:.2f} s",
-        "single_thread_value": round(fps1, 1),
-        "threads16_value": round(fps16, 1), "threads16_cores": int(used16),
+                  f"runnable: no usable numba, no params.py) over the same 1024 synthetic frames; value = the fastest of "
+                  f"{len(done)} legs: {best['frames']} frames in {best['seconds']:.2f} s on {best['threads']} OpenMP threads.  "
+                  f"Thread counts timed: {[r['threads'] for r in done]}; parallel count {usable} chosen by the {why}"
+                  + (f" ({quota:.2f} CPUs, {quota_where})" if quota is not None else f" of {n_all} CPUs ({quota_where})"),
+        "legs": done,
+        "single_thread_value": single["frames_per_s"],
+        "usable_cpus": usable, "usable_cpus_from": why, "cgroup_quota_cpus": quota,
         "allowed_cpus": n_all, "allowed_cpulist": _format_cpulist(allowed), "os_cpu_count": os.cpu_count(),
         "provenance": "a C/OpenMP PORT written for this project, orders of magnitude faster than anything the reference "
                       "itself can run on a CPU; the reference's own implementation is the Python loop below",
@@ -441,16 +513,16 @@ def _time_launches(fn, k, warm=3, warm_ms=40.0, cold=None):
     return a.elapsed_time(b) / k * 1e3
 
 
-def live_traffic(timeout_s=45.0):
+def live_traffic(timeout_s=60.0):
     """HBM bytes per launch of the headline kernel from PMC counters collected BY THIS RUN: three rocprofv3 child passes
     (FETCH_SIZE of the full entry, WRITE_SIZE of the full entry, FETCH_SIZE of the phase-1-only entry — counters never
     share a pass with anything but --kernel-trace, FETCH and WRITE need separate passes: MI355X_MICROARCH.md) over
     tools/exp_pmc.py, which launches the same 1024 seeded frames the timed region uses.  Corrections as the guide
     prescribes and tools/collect_profiles.py documents: both counters are KiB; FETCH_SIZE reports a wide (16 B/lane)
     streaming read at 1/2, so the depth stream — isolated by the phase-1-only pass — counts twice; the staging re-read
-    (4 B/lane LDS-DMA, uncalibrated) is priced at its known byte count; WRITE_SIZE is exact.  Returns a dict or None
-    (no rocprofv3, a pass failed or timed out): the caller then falls back to the tracked profiles/pmc_traffic.json and
-    says so.  Children are separate processes (this process has initialised the GPU: it must not exec)."""
+    (4 B/lane LDS-DMA, uncalibrated) is priced at its known byte count; WRITE_SIZE is exact.  The children launch over
+    ROTATION buffer sets in rotation, like the timed region.  Returns a dict, None (no rocprofv3) or {"failed": why} (a pass
+    failed or timed out): the caller then falls back to the tracked profiles/pmc_traffic.json and says so.  Children are separate processes (this process has initialised the GPU: it must not exec)."""
     import csv
     import glob
     import shutil
@@ -461,25 +533,44 @@ def live_traffic(timeout_s=45.0):
     if not os.path.exists(rocprof):
         return None
     tmp = tempfile.mkdtemp(prefix="tsdf_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", PMC_LAUNCHES="12")
+    env = dict(os.environ, TMPDIR="/tmp", PMC_LAUNCHES="12", PMC_ROTATE=str(ROTATION))
     kernel = "tsdf_fused_kernel<32, 0, false, false"
+
+    failed = []
 
     def one(counter, mode):
         d = os.path.join(tmp, counter + "_" + mode)
         e = dict(env, PMC_MODE=mode)
+        # its own session: on a timeout the whole group goes (rocprofv3 runs the program as a child — killing the launcher
+        # alone would leave a python on the GPU under the extras that follow)
         try:
-            r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                                sys.executable, os.path.join(ROOT, "tools", "exp_pmc.py")],
-                               env=e, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
-        except (subprocess.TimeoutExpired, OSError):
+            p = subprocess.Popen([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                                  sys.executable, os.path.join(ROOT, "tools", "exp_pmc.py")],
+                                 env=e, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        except OSError as err:
+            failed.append(f"{counter}/{mode}: {err}")
             return None
-        if r.returncode != 0:
+        try:
+            rc = p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            p.wait()
+            failed.append(f"{counter}/{mode}: live pass timed out after {timeout_s:.0f} s (process group killed)")
+            return None
+        if rc != 0:
+            failed.append(f"{counter}/{mode}: rocprofv3 exit code {rc}")
             return None
         vals = []
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
                     vals.append(float(row["Counter_Value"]))
+        if not vals:
+            failed.append(f"{counter}/{mode}: no row of {kernel}")
         return float(np.median(vals)) if vals else None
 
     try:
@@ -489,7 +580,7 @@ def live_traffic(timeout_s=45.0):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     if fetch is None or write is None or fetch_p1 is None:
-        return None
+        return {"failed": "; ".join(failed) or "unknown"}
     synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
     stage = 0
     for i in range(FRAMES_PER_LAUNCH):     # the staged rectangle of every frame: 4 bytes x its bounding rectangle of valid pixels
@@ -572,7 +663,7 @@ def shard_frames(synth, packing, a, b):
 def config3_sharded(be, synth, shard, packing, rank, world, launches=3):
     """This rank's pixel-balanced contiguous shard of the 76,500-crop set, resident, voxelized by `launches` launches
     (HIP events).  Replaces the subject x gesture x frame loop of pre/read_MSRA.py:51,78,98-106.  Returns
-    (frames, pixels, seconds per launch)."""
+    (frames, pixels, seconds per launch, index of the shard's first frame)."""
     lens = crop_lengths(synth)
     a, b = shard.shard_bounds(ALL_SUBJECTS, world, weights=lens)[rank]
     if be.name == "host-stub":
@@ -596,7 +687,7 @@ def config3_sharded(be, synth, shard, packing, rank, world, launches=3):
     del d, o, h, out
     if be.name == "hip":
         torch.cuda.empty_cache()
-    return b - a, int(off[-1]), sec
+    return b - a, int(off[-1]), sec, a
 
 
 def one_frame_report(pkg, synth, dev):
@@ -661,10 +752,12 @@ def one_frame_report(pkg, synth, dev):
     }
 
 
-def extras(pkg, synth, dev, td, to, th, offsets):
+def extras(pkg, synth, dev, batches, offsets):
     """The other BASELINE.json configs and the small-batch latencies, measured OUTSIDE the timed region (rank 0,
-    N=1).  Every entry says what it ran; rates are device-resident unless the entry says "streamed"."""
+    N=1).  Every entry says what it ran; rates are device-resident unless the entry says "streamed".  `batches` = the
+    timed region's resident (depth, offsets, headers, outputs) sets; everything but the rotation entry uses the first."""
     import torch.utils.data as tdata
+    td, to, th = batches[0][:3]
     ex = {}
     ex["configs[0]_one_frame"] = one_frame_report(pkg, synth, dev)
     # ---- small batches: launch latency as a training step sees it (reference batch size: 16, 3D_CNN/train.py:36)
@@ -697,30 +790,25 @@ def extras(pkg, synth, dev, td, to, th, offsets):
         if note:
             ex[name]["what"] = note
         del out
-    # The headline re-launches ONE resident batch (BASELINE configs[1]).  Part of its 315 MB of depth is then still in the
-    # 256 MB Infinity Cache when the next launch reads it: with six different batches and output buffers in rotation the
-    # same launch takes 7-8 % longer (tools/exp_mall.py: 130-133 -> 141 us; inputs alone in rotation 137.5, outputs alone
-    # 131.5).  Reported next to the headline so that nobody has to guess which of the two a consumer will see.
-    rot = [(td, to, th, pkg.voxelize(td, to, th))]
-    for k in range(1, 6):
-        dk, ok_, hk = synth.synth_batch(FRAMES_PER_LAUNCH, "full", seed0=7 * FRAMES_PER_LAUNCH * k)
-        tk = tuple(torch.from_numpy(a).to(dev) for a in (dk, ok_, hk))
-        rot.append(tk + (pkg.voxelize(*tk),))
+    # The headline's two figures once more, paired in one pass at steady state (_time_launches: 120 launches each after
+    # 40 ms of the same workload): the timed region's batches in rotation, and the first batch re-launched.  With one
+    # batch part of its 315 MB of depth is still in the 256 MiB Infinity Cache when the next launch reads it
+    # (tools/exp_mall.py: inputs alone in rotation cost +5 %, outputs alone +1 %).
     state = {"i": 0}
 
     def launch_rot():
-        a_ = rot[state["i"] % len(rot)]
+        a_ = batches[state["i"] % len(batches)]
         state["i"] += 1
         pkg.voxelize(a_[0], a_[1], a_[2], res=RES, out=a_[3])
     us_rot = _time_launches(launch_rot, 120, warm=12)
-    us_same = _time_launches(lambda: pkg.voxelize(td, to, th, res=RES, out=rot[0][3]), 120, warm=12)
+    us_same = _time_launches(lambda: pkg.voxelize(td, to, th, res=RES, out=batches[0][3]), 120, warm=12)
     ab1 = algorithmic_bytes(offsets, FRAMES_PER_LAUNCH, RES)
     ex["full_1024_six_batches_in_rotation"] = {
         "frames": FRAMES_PER_LAUNCH, "res": RES, "us_per_launch": round(us_rot, 1), "us_per_launch_same_batch": round(us_same, 1),
         "frames_per_s": round(FRAMES_PER_LAUNCH / us_rot * 1e6), "frac_of_hbm_peak": round(ab1 / us_rot / 1e3 / HBM_PEAK_GBS, 4),
-        "what": "the headline workload with SIX different resident batches and output buffers taken in rotation (4.3 GB of "
-                "distinct memory) instead of one batch re-launched: no Infinity Cache reuse of the depth rows between launches"}
-    del rot
+        "frac_of_hbm_peak_same_batch": round(ab1 / us_same / 1e3 / HBM_PEAK_GBS, 4),
+        "what": f"the headline workload ({len(batches)} resident batches and output buffer sets in rotation) and one batch "
+                "re-launched, 120 launches each, back to back in one pass"}
     # the same kernel on 4096 frames (the 1024 frames four times over): eight frames per half-workgroup instead of two, i.e.
     # what the launch's tail costs at the BASELINE batch size ("Where the headline launch's time goes")
     d4 = td.repeat(4)
@@ -955,15 +1043,29 @@ def main():
     shard = importlib.import_module("handposeestimation-with-3d-cnns_amd.shard")
     packing = importlib.import_module("handposeestimation-with-3d-cnns_amd.packing")
 
-    # this rank's batch: frames [rank*1024, (rank+1)*1024) of the seeded synthetic set
-    if dry:
-        depth = np.zeros(FRAMES_PER_GPU * 76800, np.float32)
-        offsets = np.arange(FRAMES_PER_GPU + 1, dtype=np.int64) * 76800
-        headers = np.tile(np.array([320, 240, 0, 0, 320, 240], np.int32), (FRAMES_PER_GPU, 1))
-    else:
-        depth, offsets, headers = synth.synth_batch(FRAMES_PER_GPU, "full", seed0=rank * FRAMES_PER_GPU)
-    td, to, th = be.upload(depth, offsets, headers)
-    out = be.alloc_out(td, to, th)  # allocates the outputs once
+    # This rank's ROTATION batches of 1024 seeded synthetic frames, all resident, each with its own output buffers: launch
+    # i voxelizes batch i % ROTATION.  One batch re-launched would keep part of its 315 MB of depth in the 256 MiB
+    # Infinity Cache from launch to launch (7-8 % faster: profiles/r04/mall.log) — a consumer never sees that: in
+    # pre/tsdf_numba.py:119-161 every call is a new frame.  Six batches = 4.3 GB of distinct memory per GPU.
+    # Batch k of rank r = frames [(k*world + r)*1024, +1024) of the seeded set (k = 0: what rounds 1-4 timed).
+    batches = []
+    seeds = [(k * world + rank) * FRAMES_PER_GPU for k in range(ROTATION)]
+    for k in range(ROTATION):
+        if dry:
+            depth = np.zeros(FRAMES_PER_GPU * 76800, np.float32)
+            offsets = np.arange(FRAMES_PER_GPU + 1, dtype=np.int64) * 76800
+            headers = np.tile(np.array([320, 240, 0, 0, 320, 240], np.int32), (FRAMES_PER_GPU, 1))
+        else:
+            depth, offsets, headers = synth.synth_batch(FRAMES_PER_GPU, "full", seed0=seeds[k],
+                                                        threads=min(8, len(os.sched_getaffinity(0))))
+        if k == 0:
+            depth0, offsets0, headers0 = depth, offsets, headers     # the CPU baseline's sample, the traffic bookkeeping
+        d_, o_, h_ = be.upload(depth, offsets, headers)
+        batches.append((d_, o_, h_, be.alloc_out(d_, o_, h_)))     # outputs allocated once
+    depth, offsets, headers = depth0, offsets0, headers0
+    td, to, th, out = batches[0]
+    abytes = algorithmic_bytes(offsets, FRAMES_PER_GPU, RES)     # the same for every batch: full frames, 76,800 px each
+    working_set = ROTATION * abytes
 
     def collective_barrier():
         dist.barrier() if rehearsal else dist.barrier(device_ids=[dev_index])
@@ -976,9 +1078,13 @@ def main():
             node_barrier() if node_barrier.ok else collective_barrier()
         be.sync()
 
+    turn = [0]
+
     def step():
         for _ in range(LAUNCHES_PER_STEP):
-            be.launch(td, to, th, out)
+            d_, o_, h_, out_ = batches[turn[0] % ROTATION]
+            turn[0] += 1
+            be.launch(d_, o_, h_, out_)
 
     for _ in range(args.warmup):
         step()
@@ -998,30 +1104,42 @@ def main():
 
     n_launch = args.steps * LAUNCHES_PER_STEP
     my_event_ms = be.elapsed_ms(ev0, ev1)
-    timing = gather([elapsed, my_event_ms])          # [world][2]
+
+    # the same number of launches over ONE batch (what rounds 1-4 reported as the headline): outside the timed region
+    ev2, ev3 = be.event(), be.event()
+    for _ in range(LAUNCHES_PER_STEP):
+        be.launch(td, to, th, out)
+    be.sync()
+    be.record(ev2)
+    for _ in range(n_launch):
+        be.launch(td, to, th, out)
+    be.record(ev3)
+    be.sync()
+    same_ms = be.elapsed_ms(ev2, ev3) / n_launch
+
+    timing = gather([elapsed, my_event_ms, same_ms] + seeds)          # [world][3 + ROTATION]
     elapsed_max = float(timing[:, 0].max())
 
-    # diagnostic pass (outside the timed region): per-launch event pairs -> spread of single launches
-    ev = [(be.event(), be.event()) for _ in range(50)]
-    for a, b in ev:
+    # diagnostic pass (outside the timed region): per-launch event pairs -> spread of single launches (in rotation)
+    ev = [(be.event(), be.event()) for _ in range(48)]
+    for i, (a, b) in enumerate(ev):
+        d_, o_, h_, out_ = batches[i % ROTATION]
         be.record(a)
-        be.launch(td, to, th, out)
+        be.launch(d_, o_, h_, out_)
         be.record(b)
     be.sync()
     kern_ms = np.array([be.elapsed_ms(a, b) for a, b in ev])
     launch_ms = my_event_ms / n_launch  # mean launch-to-launch time over the timed region
-    abytes = algorithmic_bytes(offsets, FRAMES_PER_GPU, RES)
 
     # ---- BASELINE configs[3]: every rank voxelizes its shard of the 76,500-crop set (no collective on the data path)
     c3 = None
     if not args.no_config3:
-        del out
-        out = None
-        f3, px3, s3 = config3_sharded(be, synth, shard, packing, rank, world)
-        g3 = gather([f3, px3, s3])                   # [world][3]
+        f3, px3, s3, a3 = config3_sharded(be, synth, shard, packing, rank, world)
+        g3 = gather([f3, px3, s3, a3])               # [world][4]
         fr, px, sec = g3[:, 0], g3[:, 1], g3[:, 2]
         c3 = {
             "frames": int(fr.sum()), "per_rank_frames": [int(v) for v in fr],
+            "per_rank_first_frame": [int(v) for v in g3[:, 3]],
             "per_rank_pixels": [int(v) for v in px],
             "per_rank_ms_per_launch": [round(float(v) * 1e3, 3) for v in sec],
             "per_rank_fps": [round(float(f / s)) for f, s in zip(fr, sec)],
@@ -1041,21 +1159,26 @@ def main():
         traffic_source = None
         traffic_parts = None
         under_profiler = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+        live_note = None
         if world == 1 and not dry and not rehearsal and not args.no_live_traffic and not under_profiler:
-            del out          # (the children need no memory of ours, but the extras below re-allocate anyway)
-            out = None
             traffic_parts = live_traffic()
-            if traffic_parts:
+            if traffic_parts and "hbm_bytes_per_launch" in traffic_parts:
                 traffic = traffic_parts["hbm_bytes_per_launch"]
-                traffic_source = ("measured by this run: three rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE, FETCH_SIZE of "
-                                  "the phase-1-only entry) over the same 1024 frames; FETCH x2 for the wide depth stream, the "
-                                  "staging re-read at its known byte count, WRITE exact")
+                traffic_source = (f"measured by this run: three rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE, FETCH_SIZE of "
+                                  f"the phase-1-only entry) over the first batch's 1024 frames held in {ROTATION} buffer sets "
+                                  "launched in rotation like the timed region; FETCH x2 for the wide depth stream, the staging "
+                                  "re-read at its known byte count, WRITE exact.  FETCH_SIZE counts what L2 requests from the "
+                                  "fabric, Infinity Cache hits included: it is the same with one batch re-launched")
+            elif traffic_parts:
+                live_note = traffic_parts.get("failed")
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if traffic is None and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 traffic_source = ("profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command from the "
-                                  "tracked profile run, NOT measured in this run (the live passes were skipped or failed)")
+                                  "tracked profile run, NOT measured in this run (the live passes were skipped or failed"
+                                  + (": " + live_note if live_note else "") + ")")
+                traffic_parts = None
             except Exception:
                 traffic = None
         line = {
@@ -1078,8 +1201,9 @@ def main():
             "config": {
                 "workload": "BASELINE configs[1]: batch 1024 synthetic 320x240 full-frame depth crops -> 32^3 "
                             "3-channel TSDF per GPU and launch, inputs resident in HBM; one step = "
-                            f"{LAUNCHES_PER_STEP} back-to-back fused launches of that batch",
-                "frames_per_launch": FRAMES_PER_LAUNCH, "launches_per_step": LAUNCHES_PER_STEP,
+                            f"{LAUNCHES_PER_STEP} back-to-back fused launches, each over the next of {ROTATION} resident "
+                            "batches of 1024 frames (no batch is re-read from a cache)",
+                "frames_per_launch": FRAMES_PER_LAUNCH, "launches_per_step": LAUNCHES_PER_STEP, "batches_in_rotation": ROTATION,
                 "frames_per_gpu_per_step": FRAMES_PER_LAUNCH * LAUNCHES_PER_STEP, "res": RES, "layout": "czyx",
                 "parallelism": f"frame-sharded x{world}, no collective",
             },
@@ -1090,14 +1214,22 @@ def main():
                 # every rank's own roofline fraction: its algorithmic bytes per second over the 8 TB/s of ITS GPU
                 "frac_of_hbm_peak_events": [round(abytes * n_launch / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                             for v in timing[:, 1]],
-                "what": "every rank's own timed region: HIP events on its launch stream, and host wall between the two barriers",
+                "frac_of_hbm_peak_same_batch": [round(abytes / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for v in timing[:, 2]],
+                "batch_seed0": [[int(v) for v in row[3:]] for row in timing],
+                "what": "every rank's own timed region: HIP events on its launch stream, and host wall between the two barriers; "
+                        "batch_seed0 = the first seed of each of the rank's resident batches (1024 consecutive seeds each)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_source, "traffic_parts": traffic_parts,
+                "what": f"the timed region itself: every launch takes the next of {ROTATION} resident batches and output buffer sets "
+                        f"({working_set / 1e9:.2f} GB of distinct memory >> the 256 MiB Infinity Cache), so no launch finds its input "
+                        "in a cache; frac_same_batch = the same number of launches over ONE batch (rounds 1-4's headline)",
+                "frac_same_batch": round(abytes / (same_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "launch_ms_mean_same_batch": round(float(same_ms), 4),
+                "rotation": ROTATION, "working_set_bytes": working_set,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
-                "working_set_bytes": abytes,
                 "kernel": be.kernel_name(FRAMES_PER_LAUNCH, RES), "algorithmic_bytes_per_launch": abytes,
                 "launch_ms_mean": round(mean_ms, 4),
                 "single_launch_ms_median": round(float(np.median(kern_ms)), 4),
@@ -1111,16 +1243,12 @@ def main():
         ex = {}
         if c3 is not None:
             ex["configs[3]_sharded"] = c3
-        if world == 1 and not args.no_cpu_baseline and not dry:
-            line["cpu_baseline"] = cpu_baseline(depth, offsets, headers)
+        if world == 1 and not args.no_cpu_baseline:
+            # (a dry run times the oracle on its all-background frames for a moment: the object's shape, not a number)
+            line["cpu_baseline"] = (cpu_baseline(depth, offsets, headers, 0.05, 0.05, legs_override=[1, 2]) if dry
+                                    else cpu_baseline(depth, offsets, headers))
         if world == 1 and not args.no_extras and not rehearsal:
-            if out is None:
-                out = be.alloc_out(td, to, th)
-            ex.update(extras(be.pkg, synth, be.dev, td, to, th, offsets))
-            r6 = ex.get("full_1024_six_batches_in_rotation")
-            if r6:   # (the same launch without Infinity Cache reuse of its input between launches: see the extra)
-                line["roofline"]["launch_ms_six_batches_in_rotation"] = round(r6["us_per_launch"] * 1e-3, 4)
-                line["roofline"]["frac_six_batches_in_rotation"] = r6["frac_of_hbm_peak"]
+            ex.update(extras(be.pkg, synth, be.dev, batches, offsets))
             sc = stream_ceilings()
             if sc:
                 ex["stream_ceilings"] = sc

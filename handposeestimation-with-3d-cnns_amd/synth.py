@@ -57,21 +57,26 @@ def synth_frame(seed: int, kind: str = "full"):
     return header, np.ascontiguousarray(depth.reshape(-1))
 
 
-def synth_batch(n: int, kind: str = "full", seed0: int = 0):
+def synth_batch(n: int, kind: str = "full", seed0: int = 0, threads: int = 1):
     """n frames packed back to back.
 
     Returns (depth float32[sum N_i], offsets int64[n+1], headers int32[n,6]) - exactly
-    the three input arrays of ``tsdf_voxelize_hip`` (include/tsdf.h).
+    the three input arrays of ``tsdf_voxelize_hip`` (include/tsdf.h).  ``threads`` > 1
+    generates the frames on a thread pool (numpy releases the GIL in the fills); every
+    frame has its own seeded generator, so the result does not depend on it.
     """
+    if threads > 1 and n > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            frames = list(ex.map(lambda i: synth_frame(seed0 + i, kind), range(n)))
+    else:
+        frames = [synth_frame(seed0 + i, kind) for i in range(n)]
     headers = np.empty((n, 6), dtype=np.int32)
-    chunks = []
     offsets = np.zeros(n + 1, dtype=np.int64)
-    for i in range(n):
-        h, d = synth_frame(seed0 + i, kind)
+    for i, (h, d) in enumerate(frames):
         headers[i] = h
-        chunks.append(d)
         offsets[i + 1] = offsets[i] + d.size
-    depth = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.float32)
+    depth = np.concatenate([d for _, d in frames]) if frames else np.zeros(0, dtype=np.float32)
     return depth, offsets, headers
 
 
