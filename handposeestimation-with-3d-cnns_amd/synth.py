@@ -57,6 +57,50 @@ def synth_frame(seed: int, kind: str = "full"):
     return header, np.ascontiguousarray(depth.reshape(-1))
 
 
+def synth_variant(seed: int, bbox=(0, 0, IMG_W, IMG_H), base: float = 450.0, rad: float = 60.0, centre=None,
+                  keep: float = 0.99, bulge: float = 40.0, ecc: float = 0.9, noise: float = 1.0, sign: str = "pos"):
+    """One frame outside the two benchmark distributions -> (header int32[6], depth float32[b_w*b_h]): the same blob
+    model as synth_frame with every parameter explicit, for the parity fixtures and the fuzzer.
+
+    bbox    (left, top, right, bottom) inside the 320x240 image;
+    base    depth of the blob's rim in mm (150 = a hand at the lens, 1500 = across the room);
+    rad     x radius of the blob in pixels (``ecc`` shrinks the y radius); ``centre`` = (cx, cy) in image pixels, default
+            a seeded position that keeps the blob inside the bbox (a centre near a bbox edge cuts the blob);
+    keep    probability that a foreground pixel keeps its depth (0.01 = a very sparse crop, 1.0 = no holes);
+    sign    "pos": depths as measured; "neg": all negated; "halves": the left half of the valid pixels negated;
+            "checker": negated where (x + y) is odd.  The reference accepts any |d| >= 1 (pre/tsdf_numba.py:43,
+            pre/tsdf_for.py:90) and maps d to z = -d, so a mixed-sign crop puts z = 0 INSIDE the grid: q = -F / v_z
+            changes sign, and grows without bound, across it.
+    """
+    rng = np.random.default_rng(987654 + int(seed))
+    l, t, r, b = (int(v) for v in bbox)
+    if not (0 <= l < r <= IMG_W and 0 <= t < b <= IMG_H):
+        raise ValueError("bbox must lie inside the 320x240 image")
+    if centre is None:
+        rx, ry = min(rad, 0.5 * (r - l)), min(rad * ecc, 0.5 * (b - t))
+        cx = float(rng.uniform(l + rx, r - rx)) if r - l > 2 * rx else 0.5 * (l + r)
+        cy = float(rng.uniform(t + ry, b - ry)) if b - t > 2 * ry else 0.5 * (t + b)
+    else:
+        cx, cy = float(centre[0]), float(centre[1])
+    xs = np.arange(l, r, dtype=np.float64)[None, :]
+    ys = np.arange(t, b, dtype=np.float64)[:, None]
+    rr = ((xs - cx) / rad) ** 2 + ((ys - cy) / (rad * ecc)) ** 2
+    depth = base - bulge * np.sqrt(np.clip(1.0 - rr, 0.0, 1.0))
+    depth = depth + rng.normal(0.0, noise, size=depth.shape)
+    kept = rng.random(depth.shape) < keep
+    depth = np.where((rr < 1.0) & kept, depth, 0.0)
+    if sign == "neg":
+        depth = -depth
+    elif sign == "halves":
+        depth = np.where(xs + 0 * ys < cx, -depth, depth)
+    elif sign == "checker":
+        depth = np.where(((xs + ys).astype(np.int64) & 1) == 1, -depth, depth)
+    elif sign != "pos":
+        raise ValueError("sign must be pos, neg, halves or checker")
+    header = np.array([IMG_W, IMG_H, l, t, r, b], dtype=np.int32)
+    return header, np.ascontiguousarray(depth.astype(np.float32).reshape(-1))
+
+
 def synth_batch(n: int, kind: str = "full", seed0: int = 0, threads: int = 1):
     """n frames packed back to back.
 

@@ -214,3 +214,42 @@ def test_config4_64cubed_with_fused_augmentation(pkg, synth):
     ident = torch.from_numpy(pkg.augment.identity_affines(64)).to(d)
     a0 = pkg.voxelize_aug(td[: off[64]], to[:65].contiguous(), th[:64].contiguous(), ident, res=64)
     assert torch.equal(a0.max_l, plain.max_l[:64]) and float((a0.tsdf - plain.tsdf[:64]).abs().max()) <= TOL
+
+
+def test_bench_one_rank_through_torchrun_prints_the_plain_line():
+    """The N = 1 point of a scaling run is launched through torch.distributed.run (world 1, RCCL process group of one
+    rank), the round's BENCH run as plain `python bench.py`: both on the real GPU, short, and the two lines must carry the
+    same keys — `roofline` and `cpu_baseline` included — and agree on the rate (tests/test_bench_ranks.py does the same
+    without a GPU)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-extras", "--no-live-traffic"]
+    env = {k: v for k, v in os.environ.items() if k not in ("TORCHELASTIC_RUN_ID", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    lines = []
+    for cmd in ([sys.executable] + tail,
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                 "--master-port", str(port)] + tail):
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1
+        lines.append(json.loads(js[0]))
+    plain, tr = lines
+    assert plain["dist_backend"] is None and tr["dist_backend"] == "nccl" and tr["dist_world_size"] == 1
+    for j in lines:
+        assert j["n_gpus"] == 1 and "dry_run" not in j and "rehearsal" not in j
+        assert j["roofline"]["rotation"] >= 6 and j["roofline"]["working_set_bytes"] >= 4e9
+        assert 0.3 < j["roofline"]["frac"] <= j["roofline"]["frac_same_batch"] * 1.02 < 1.0
+        assert j["cpu_baseline"]["value"] == max(leg["frames_per_s"] for leg in j["cpu_baseline"]["legs"])
+        assert j["extras"]["configs[3]_sharded"]["per_rank_frames"] == [N_ALL]
+    assert set(plain) == set(tr) and set(plain["roofline"]) == set(tr["roofline"]) and set(plain["cpu_baseline"]) == set(tr["cpu_baseline"])
+    assert abs(plain["value"] - tr["value"]) / plain["value"] < 0.05

@@ -32,13 +32,54 @@ def test_voxels_match_reference_loop_numba_typing(golden_dir, name):
 
 @pytest.mark.parametrize("name", NAMES)
 def test_voxels_within_tol_of_reference_loop_as_it_runs(golden_dir, name):
-    """a4': the loop as it runs today (float32 scalars under numpy 2) differs from the numba
-    typing only by rounding (<= 1e-5) except where a pixel index / threshold flips; the golden
-    records how many voxels flip (0 on every committed fixture)."""
+    """a4': the loop as it runs today (float32 scalars under numpy 2) differs from the numba typing only by rounding
+    (<= 1e-5) except where a pixel index / threshold / sign test flips.  The golden records how many
+    voxels flip, the `*_flip` fixtures were searched for so that the count is not zero: the oracle — float64, the numba
+    typing — must disagree with loop32 on exactly those voxels and agree with loop64 everywhere."""
     g = load(golden_dir, name)
     out = oracle.voxels(g["depth"], g["header"], g["vox_ori"], g["voxel_len"], g["trunc"])
-    bad = (np.abs(out - g["loop32"]) > 1e-5).any(axis=0).sum()
-    assert bad == int(g["n_flip"]) == 0
+    bad = (np.abs(out - g["loop32"]) > 1e-5).any(axis=0)
+    assert bad.sum() == int(g["n_flip"])
+    assert (int(g["n_flip"]) > 0) == name.endswith("_flip")
+    np.testing.assert_array_equal(bad, (np.abs(g["loop64"] - g["loop32"]) > 1e-5).any(axis=0))
+
+
+def test_the_golden_set_covers_what_the_survey_called_hard(golden_dir):
+    """>= 20 frames; at least two with float32/float64 flips, and every kind of flip present among them (a pixel index
+    one off, and a voxel one typing rejects or truncates and the other does not); hands at 150 mm and at 1,500 mm, a
+    bbox far off the principal point, ~1 % valid and fully valid crops, negative and mixed-sign depths (a grid that
+    straddles the camera plane)."""
+    gs = {n: load(golden_dir, n) for n in NAMES}
+    assert len(gs) >= 20
+    flips = [n for n, g in gs.items() if int(g["n_flip"]) > 0]
+    assert len(flips) >= 2 and sum(int(gs[n]["n_flip"]) for n in flips) >= 20
+    mid_z = {n: float(g["mid_p"][2]) for n, g in gs.items()}
+    assert min(abs(z) for z in mid_z.values() if abs(z) > 50) < 160 and min(mid_z.values()) < -1400
+    assert any(z > 100 for z in mid_z.values())                                     # all-negative depths: z = +d
+    straddle = [n for n, g in gs.items() if abs(mid_z[n]) < float(g["max_l"]) / 2]  # z = 0 inside the cube
+    assert len(straddle) >= 3
+    for n in straddle:
+        g = gs[n]
+        vz = g["vox_ori"][2] + np.arange(32) * g["voxel_len"]
+        assert (vz < 0).any() and (vz > 0).any()
+        nz = (g["loop64"] != 0).any(axis=0)           # [z,y,x]: valid voxels on BOTH sides of the camera plane
+        assert nz[vz < 0].any() and nz[vz > 0].any(), n
+    frac = {n: int(g["n_valid"]) / g["depth"].size for n, g in gs.items()}
+    assert min(frac.values()) < 0.012 and max(frac.values()) == 1.0
+    off = {n: max(abs(int(g["header"][2]) + int(g["header"][4]) - 320), abs(int(g["header"][3]) + int(g["header"][5]) - 240)) / 2
+           for n, g in gs.items()}
+    assert max(off.values()) >= 100                                                  # bbox centre >= 100 px off (160, 120)
+    # kinds of flip, voxel by voxel: another pixel gathered (both typings write a value, the values differ), a voxel only the
+    # float32 loop writes, a voxel only the float64 loop writes
+    kinds = {"value": 0, "only32": 0, "only64": 0}
+    for n in flips:
+        g = gs[n]
+        bad = (np.abs(g["loop32"] - g["loop64"]) > 1e-5).any(axis=0)
+        a, b = (g["loop32"] != 0).any(axis=0), (g["loop64"] != 0).any(axis=0)
+        kinds["value"] += int((bad & a & b).sum())
+        kinds["only32"] += int((bad & a & ~b).sum())
+        kinds["only64"] += int((bad & ~a & b).sum())
+    assert all(v > 0 for v in kinds.values()), kinds
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run, far beyond what the test-suite holds (GPU box; the oracle runs on the host cores):
-random geometry (widths 1..645, heights 1..240, bboxes anywhere, sparse..dense, blobs and scatter, negative / sub-threshold
-depths, NaN sprinkles), random camera constants, both layouts, R in {16,32,40,64}, fused (n > 128) and split (n <= 128)
+random geometry (widths 1..645, heights 1..240, bboxes anywhere, sparse..dense, blobs and scatter, negative / mixed-sign /
+sub-threshold depths, NaN sprinkles), random camera constants, both layouts, R in {16,32,40,64}, fused (n > 128) and split (n <= 128)
 kernels, the augmented entry with reference-distribution maps, labels.  Checks: status / max_l / mid_p / labels bit exact,
 volume <= 1e-5.      python tools/fuzz_parity.py [rounds=40] [seed=1]"""
 import importlib, os, sys, time
@@ -34,8 +34,11 @@ def make_frames(n):
         d[~keep] = 0.0
         r = rng.random()
         if r < 0.08: d *= -1.0
-        elif r < 0.14: d[rng.random((bh, bw)) < 0.1] = 0.75
-        elif r < 0.18: d[rng.random((bh, bw)) < 0.05] = np.nan
+        elif r < 0.13:   # mixed signs: the grid straddles the camera plane z = 0 (q = -F / v_z changes sign inside it)
+            flip = (np.arange(bw)[None, :] < rng.uniform(0, bw)) if rng.random() < 0.5 else (rng.random((bh, bw)) < 0.5)
+            d = np.where(flip, -d * np.float32(rng.choice([1.0, 0.3, 2.5])), d).astype(np.float32)
+        elif r < 0.18: d[rng.random((bh, bw)) < 0.1] = 0.75
+        elif r < 0.22: d[rng.random((bh, bw)) < 0.05] = np.nan
         frames.append((np.array([640, 480, left, top, left + bw, top + bh], np.int32), d.reshape(-1)))
     headers = np.stack([f[0] for f in frames])
     offsets = np.zeros(n + 1, np.int64); offsets[1:] = np.cumsum([f[1].size for f in frames])

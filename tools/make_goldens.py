@@ -148,7 +148,7 @@ def run_reference_aug(outdir):
 
 def run_reference_joint_nor(outdir, golden_scales):
     """joint_nor_ref.npz: the reference's own normalize (pre/joint_nor.py:8-18) run on float32 [n,21,3] labels.
-    Frames 0..7 use the max_l / mid_p the reference's tsdf_f produced for the volume goldens (same order as
+    The first frames use the max_l / mid_p the reference's tsdf_f produced for the volume goldens (same order as
     MANIFEST.txt), the rest seeded scales; some joints lie outside the cube so that the clamp of
     3D_CNN/train.py:241-242 (applied by the test to these reference values) has something to do.  The reference
     stores its float32 results in a float64 array; they are kept as float64 here, untouched."""
@@ -291,16 +291,56 @@ np.savez(sys.argv[2], **out)
               % (total, int(z["train_len"]), int(z["test_len"]), list(z["train_item_types"])))
 
 
-def main(only=None):
-    outdir = os.path.join(ROOT, "tests", "golden")
-    os.makedirs(outdir, exist_ok=True)
-    if only:   # regenerate some of the reference-run fixtures without touching the volume goldens
-        for name in only:
-            {"aug": run_reference_aug, "io": run_reference_io, "dataset": run_reference_dataset}[name](outdir)
-        return
-    run_reference_aug(outdir)
-    run_reference_io(outdir)
-    run_reference_dataset(outdir)
+# Frames outside the two benchmark distributions (synth.synth_variant): name -> (seed, parameters).  The *_flip seeds
+# were FOUND by scanning seeds 0..39 of each family with a vectorised float32 emulation of the loop (bit-identical to
+# the reference's loop32 on every fixture: checked below) for frames on which the loop as it runs today (float32
+# scalars) and the numba typing (float64) disagree by more than 1e-5 somewhere — a pixel index `int(v_x*q + 160)`
+# (pre/tsdf_numba.py:31-32), the `> 1` truncation test or the sign test falling the other way (hard part
+# #1).  About one frame in fifty has such voxels.  They are carried with the float64 expectation (loop64) AND the
+# float32 one (loop32); n_flip counts the voxels that differ.
+VARIANTS = [
+    ("near_150", 0, dict(bbox=(40, 20, 300, 230), base=150.0, rad=100.0, bulge=30.0)),          # a hand at the lens
+    ("far_1500", 0, dict(bbox=(130, 90, 190, 150), base=1500.0, rad=18.0, bulge=25.0)),         # across the room
+    ("far_1500_flip", 4, dict(bbox=(130, 90, 190, 150), base=1500.0, rad=18.0, bulge=25.0)),
+    ("corner_tl", 0, dict(bbox=(0, 0, 110, 100), base=380.0, rad=45.0)),                        # far off the principal point
+    ("corner_tl_flip", 11, dict(bbox=(0, 0, 110, 100), base=380.0, rad=45.0)),
+    ("corner_br_flip", 1, dict(bbox=(200, 130, 320, 240), base=520.0, rad=50.0)),
+    ("sparse_1pct", 0, dict(bbox=(60, 40, 260, 200), base=420.0, rad=75.0, keep=0.012)),        # ~1 % of the blob valid
+    ("sparse_1pct_flip", 27, dict(bbox=(60, 40, 260, 200), base=420.0, rad=75.0, keep=0.012)),
+    ("dense", 0, dict(bbox=(100, 70, 220, 170), base=400.0, rad=200.0, keep=1.0)),              # every bbox pixel valid
+    ("neg_all_flip", 2, dict(bbox=(80, 60, 240, 200), base=450.0, rad=60.0, sign="neg")),       # z = +d: behind the camera
+    # mixed-sign depths: the grid straddles z = 0, q = -F / v_z changes sign inside it (pre/tsdf_numba.py:30-41)
+    ("mixed_halves", 0, dict(bbox=(90, 50, 230, 190), base=300.0, rad=60.0, sign="halves")),
+    ("mixed_checker", 0, dict(bbox=(90, 50, 230, 190), base=250.0, rad=55.0, sign="checker")),
+    ("mixed_halves_near", 3, dict(bbox=(120, 80, 200, 160), base=40.0, rad=35.0, bulge=10.0, sign="halves")),
+]
+FLIP_CROP_SEED = 20     # synth_frame(20, "crop"): the one flip frame among seeds 0..59 of the benchmark distributions
+
+
+def loop32_emulation(depth, header, vox_ori, voxel_len, trunc):
+    """The reference loop as it runs under numpy 2 (float32 scalar arithmetic), vectorised — ONLY a search tool for
+    flip frames and a cross-check of itself against the reference's loop32 below; nothing is pinned to it."""
+    F = np.float32(241.42)
+    l, t, r, b = [int(v) for v in header[2:6]]
+    step = (np.arange(32) * np.float32(voxel_len)).astype(np.float32)
+    X, Y, Z = np.meshgrid(vox_ori[0] + step, vox_ori[1] + step, vox_ori[2] + step, indexing="ij")
+    with np.errstate(all="ignore"):
+        coeff = -F / Z
+        px = np.trunc(X * coeff + np.float32(160)).astype(np.int64)
+        py = np.trunc(-Y * coeff + np.float32(120)).astype(np.int64)
+    ok = (px >= l) & (px < r) & (py >= t) & (py < b)
+    pd = depth[np.where(ok, (py - t) * (r - l) + px - l, 0)]
+    ok &= np.abs(pd) >= 1
+    c1 = pd / F
+    wx, wy, wz = (px - 160).astype(np.float32) * c1, (-(py - 120)).astype(np.float32) * c1, -pd
+    tx, ty, tz = np.abs(X - wx) / trunc, np.abs(Y - wy) / trunc, np.abs(Z - wz) / trunc
+    far = np.sqrt(tx * tx + ty * ty + tz * tz) > 1
+    sgn = np.where(wz > Z, -1, 1)
+    out = np.stack([np.where(far, 1, np.minimum(v, 1)) * sgn for v in (tx, ty, tz)]).astype(np.float32) * ok
+    return np.ascontiguousarray(out.transpose(0, 3, 2, 1))
+
+
+def volume_frames():
     frames = []
     for s in (0, 1, 2):
         h, d = synth.synth_frame(s, "full")
@@ -309,23 +349,44 @@ def main(only=None):
         h, d = synth.synth_frame(s, "crop")
         frames.append((f"crop_{s}", h, d))
     frames += special_frames()
+    h, d = synth.synth_frame(FLIP_CROP_SEED, "crop")
+    frames.append((f"crop_{FLIP_CROP_SEED}_flip", h, d))
+    for name, seed, kw in VARIANTS:
+        h, d = synth.synth_variant(seed, **kw)
+        frames.append((name, h, d))
+    return frames
+
+
+def run_volumes(outdir):
     names = []
     scales = []
-    for name, h, d in frames:
+    for name, h, d in volume_frames():
         g = run_reference(h, d)
+        emu = loop32_emulation(d, h, g["vox_ori"], g["voxel_len"], g["trunc"])
+        assert np.array_equal(emu, g["loop32"]), f"{name}: the search emulation is not the reference's loop32"
+        assert (int(g["n_flip"]) > 0) == name.endswith("_flip"), (name, int(g["n_flip"]))
         scales.append((g["max_l"], g["mid_p"]))
         np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **g)
         names.append(name)
-        print(f"{name}: bbox {h[4]-h[2]}x{h[5]-h[3]} valid {int(g['n_valid'])} max_l {float(g['max_l']):.4f} "
-              f"flips(f32 vs f64 loop) {int(g['n_flip'])} "
-              f"|loop32-loop64|max(non-flip) "
-              f"{float(np.abs(g['loop32']-g['loop64'])[np.abs(g['loop32']-g['loop64'])<=1e-5].max()):.2e}")
+        dd = np.abs(g["loop32"] - g["loop64"])
+        print(f"{name}: bbox {h[4]-h[2]}x{h[5]-h[3]} valid {int(g['n_valid'])} of {d.size} max_l {float(g['max_l']):.4f} "
+              f"mid_z {float(g['mid_p'][2]):.1f} nonzero voxels {int((g['loop64'] != 0).any(axis=0).sum())} "
+              f"flips(f32 vs f64 loop) {int(g['n_flip'])} |loop32-loop64|max(non-flip) {float(dd[dd <= 1e-5].max()):.2e}")
     run_reference_joint_nor(outdir, scales)
     with open(os.path.join(outdir, "MANIFEST.txt"), "w") as f:
         f.write("# written by tools/make_goldens.py from /root/reference/pre/{tsdf_for,process,joint_nor}.py\n")
         f.write("# numpy %s\n" % np.__version__)
+        f.write("# *_flip: frames on which the float32 loop and the float64 (numba-typed) loop disagree somewhere (n_flip > 0)\n")
         for n in names:
             f.write(n + "\n")
+
+
+def main(only=None):
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    steps = {"aug": run_reference_aug, "io": run_reference_io, "dataset": run_reference_dataset, "volumes": run_volumes}
+    for name in (only or list(steps)):   # --only: some of the fixtures, the others untouched (npz files carry time stamps)
+        steps[name](outdir)
 
 
 if __name__ == "__main__":
@@ -333,5 +394,5 @@ if __name__ == "__main__":
 
     ap = argparse.ArgumentParser(description="Regenerate tests/golden/*.npz by running the reference's own code "
                                              "(needs /root/reference).")
-    ap.add_argument("--only", default="", help="comma list of aug,io,dataset: just these fixtures")
+    ap.add_argument("--only", default="", help="comma list of aug,io,dataset,volumes: just these fixtures")
     main([x for x in ap.parse_args().only.split(",") if x])
