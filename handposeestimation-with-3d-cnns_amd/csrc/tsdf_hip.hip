@@ -1164,6 +1164,16 @@ __device__ __forceinline__ void phase2(const Grid &g, const CamK &cam, const Vox
 // restated operation by operation in the oracle) is written in exactly this form.
 // atab layout: [axis][index][4] = { fl(inv[4*row + axis] * (ori_axis + index*voxel_len)) for row 0..2 — the z
 // entries + b_row —, (ori_axis + index*voxel_len) - fwd_b[axis] }.
+// The table of the axis the LANES index (x for LAYOUT 0, z for LAYOUT 1) is stored lane-major: a lane reads the entries
+// of its four voxels 4i..4i+3 — 8 pieces of 16 bytes — and the 16 lanes of a grid row read them together, so piece
+// (j, half) of all lanes is one contiguous run: double offset of entry `idx`, value `row` (0..3).  With the plain
+// [index][4] layout those reads were 128 bytes apart from lane to lane: ds_read_b128 banks 4-way, and since the voxel pass
+// works in (slab x 2-slice) units a wave re-reads them every other unit — SQ_LDS_BANK_CONFLICT went from 20 M to 70 M
+// cycles per launch between rounds 3 and 4 although the LDS instruction count fell.
+__device__ __forceinline__ int lane_slot(int idx, int row, int R4) {
+  return ((2 * (idx & 3) + (row >> 1)) * R4 + (idx >> 2)) * 2 + (row & 1);
+}
+
 __device__ __forceinline__ double uniform64(double v) {  // a wave-uniform float64 -> scalar registers
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
@@ -1248,21 +1258,22 @@ __device__ __forceinline__ void phase2_aug(const Grid &g, const CamK &cam, const
       // (A_i0 x' + A_i1 y') for its 4 voxels, LAYOUT 1 (y, z fixed) keeps the z bracket — so a voxel costs ONE add
       // per row of the map.  The same goes for v' - b of the distance terms: the fixed axes' live in registers
       // (vbf), the slice's comes from its table entry.
+      // (The lanes' own axis is read from the lane-major image of its table — see lane_slot —: 16-byte pieces, the 16
+      // lanes of a row side by side, so the eight ds_read_b128 of a slab change are conflict-free.)
+      const LdsCD tl = LAYOUT == 0 ? tabx : tabz;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        const LdsCD lo = tl + lane_slot(f4i + j, 0, R4), hi = tl + lane_slot(f4i + j, 2, R4);
         if constexpr (LAYOUT == 0) {
-          const LdsCD tx = tabx + 4 * (f4i + j);
-          pre[j][0] = tx[0] + ty0;
-          pre[j][1] = tx[1] + ty1;
-          pre[j][2] = tx[2] + ty2;
-          vbf[j] = tx[3];                    // v'_x - b_x
+          pre[j][0] = lo[0] + ty0;
+          pre[j][1] = lo[1] + ty1;
+          pre[j][2] = hi[0] + ty2;
         } else {
-          const LdsCD tzp = tabz + 4 * (f4i + j);
-          pre[j][0] = tzp[0];
-          pre[j][1] = tzp[1];
-          pre[j][2] = tzp[2];
-          vbf[j] = tzp[3];                   // v'_z - b_z
+          pre[j][0] = lo[0];
+          pre[j][1] = lo[1];
+          pre[j][2] = hi[0];
         }
+        vbf[j] = hi[1];                      // v' - b of the lanes' own axis (x for LAYOUT 0, z for LAYOUT 1)
       }
       // Which division (neg_focal_over): v_z of a lane's voxel is fl(pre + slice term), monotone in the slice index
       // (every rounding is), so the pass's two end slices bound it; same sign and mid-range at both ends -> mid-range
@@ -1743,11 +1754,13 @@ __device__ __forceinline__ void fill_tables(PG &pg, const Grid &g, const CamK &c
       const int axis = e / (4 * R), rem = e - axis * 4 * R, i = rem >> 2, row = rem & 3;
       const double o_a = axis == 0 ? ox : (axis == 1 ? oy : oz);
       const double vp = o_a + (double)i * vl;                    // :26-28
+      // the axis the lanes index is stored lane-major (lane_slot), the two the slices / slabs index as [index][4]
+      const int at = axis == (LAYOUT == 0 ? 0 : 2) ? 4 * R * axis + lane_slot(i, row, R / 4) : e;
       if (row < 3) {
         const double prod = inv[4 * row + axis] * vp;
-        pg.atab[e] = axis == 2 ? prod + inv[4 * row + 3] : prod;   // the z entries carry the translation
+        pg.atab[at] = axis == 2 ? prod + inv[4 * row + 3] : prod;   // the z entries carry the translation
       } else {
-        pg.atab[e] = vp - xf[4 * axis + 3];
+        pg.atab[at] = vp - xf[4 * axis + 3];
       }
     }
   }
