@@ -6,6 +6,7 @@ implementation (the oracle under oracle/ is test infrastructure only).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 
@@ -66,27 +67,25 @@ class TsdfLabels(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 INLINE_INDEX_MAX = 32   # TSDF_INLINE_INDEX_MAX of include/tsdf.h
 
+# The debug build of the same sources (make -C csrc debug: -DTSDF_DEBUG_HOOKS): everything the product exports plus the
+# test hooks of include/tsdf_debug.h.  Never loaded unless somebody asks for a hook.
+DEBUG_LIB_PATH = os.path.join(os.path.dirname(_HERE), "build", "libtsdf_hip_debug.so")
+
 _lib = None
+_debug_lib = None
 
 
-def load():
-    """Load libtsdf_hip.so once; raise loudly if it is not there."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C handposeestimation-with-3d-cnns_amd/csrc`. There is no CPU fallback."
-        )
-    L = ctypes.CDLL(LIB_PATH)
+def _bind(L, path: str):
+    """Declare the argument / result types of every entry point of include/tsdf.h on a loaded library."""
     vp = ctypes.c_void_p
     cam_p = ctypes.POINTER(TsdfCam)
     L.tsdf_version.restype = ctypes.c_int
     L.tsdf_version.argtypes = []
+    if L.tsdf_version() != ABI_VERSION:
+        raise ImportError(f"{path} has ABI version {L.tsdf_version()}, this package needs {ABI_VERSION}: rebuild it")
     L.tsdf_strerror.restype = ctypes.c_char_p
     L.tsdf_strerror.argtypes = [ctypes.c_int]
     L.tsdf_resolution_supported.restype = ctypes.c_int
@@ -126,20 +125,59 @@ def load():
     L.tsdf_normalize_joints_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.tsdf_denormalize_joints_hip.restype = ctypes.c_int
     L.tsdf_denormalize_joints_hip.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
-    L.tsdf_debug_pixmap_hip.restype = ctypes.c_int
-    L.tsdf_debug_pixmap_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, cam_p, ctypes.c_int, vp,
-                                        vp, vp, vp, vp]
     L.tsdf_stream_release.restype = ctypes.c_int
     L.tsdf_stream_release.argtypes = [vp]
-    if hasattr(L, "tsdf_describe_launch"):   # ABI v6 (the version check below reports an older library)
-        L.tsdf_describe_launch.restype = ctypes.c_int
-        L.tsdf_describe_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
-        L.tsdf_debug_set_queue_word.restype = ctypes.c_int
-        L.tsdf_debug_set_queue_word.argtypes = [vp, ctypes.c_uint64]
-    if L.tsdf_version() != ABI_VERSION:
-        raise ImportError(f"{LIB_PATH} has ABI version {L.tsdf_version()}, this package needs {ABI_VERSION}: rebuild it")
-    _lib = L
+    L.tsdf_describe_launch.restype = ctypes.c_int
+    L.tsdf_describe_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     return L
+
+
+def load():
+    """Load libtsdf_hip.so once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C handposeestimation-with-3d-cnns_amd/csrc`. There is no CPU fallback."
+        )
+    _lib = _bind(ctypes.CDLL(LIB_PATH), LIB_PATH)
+    return _lib
+
+
+def load_debug():
+    """The debug build (include/tsdf_debug.h): the whole ABI plus tsdf_debug_pixmap_hip / tsdf_debug_set_queue_word, and
+    TSDF_XCHG_POLLS read from the environment.  A library image of its own, with its own device-side state."""
+    global _debug_lib
+    if _debug_lib is not None:
+        return _debug_lib
+    if not os.path.exists(DEBUG_LIB_PATH):
+        raise ImportError(f"{DEBUG_LIB_PATH} not found: build it with `make -C handposeestimation-with-3d-cnns_amd/csrc debug` "
+                          "(__graft_entry__.build() does)")
+    L = _bind(ctypes.CDLL(DEBUG_LIB_PATH), DEBUG_LIB_PATH)
+    vp = ctypes.c_void_p
+    L.tsdf_debug_pixmap_hip.restype = ctypes.c_int
+    L.tsdf_debug_pixmap_hip.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(TsdfCam),
+                                        ctypes.c_int, vp, vp, vp, vp, vp]
+    L.tsdf_debug_set_queue_word.restype = ctypes.c_int
+    L.tsdf_debug_set_queue_word.argtypes = [vp, ctypes.c_uint64]
+    _debug_lib = L
+    return L
+
+
+@contextlib.contextmanager
+def using_debug_library():
+    """Inside the block every call of this package goes through the debug build instead of the product (tests that need a
+    hook and the launches it acts on in ONE library image).  Not thread-safe; objects that cached the library at
+    construction (dataset loaders) keep theirs."""
+    global _lib
+    prev = _lib
+    _lib = load_debug()
+    try:
+        yield _lib
+    finally:
+        _lib = prev
 
 
 def check(status: int, what: str):

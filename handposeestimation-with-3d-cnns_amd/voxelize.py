@@ -313,9 +313,10 @@ def release_stream(stream=None) -> None:
 
 def voxel_pixels(depth: torch.Tensor, offsets: torch.Tensor, headers: torch.Tensor, res: int = 32,
                  layout: str = "czyx", grid: Optional[torch.Tensor] = None, cam: Optional[_lib.TsdfCam] = None):
-    """Diagnostic (``tsdf_debug_pixmap_hip``): the voxelizer together with the pixel every voxel gathers.
-    Returns ``(tsdf, pixmap int32[n,R,R,R] indexed [z,y,x], status)``; pixmap values as in include/tsdf.h."""
-    L = _lib.load()
+    """Diagnostic (``tsdf_debug_pixmap_hip``, include/tsdf_debug.h): the voxelizer together with the pixel every voxel
+    gathers.  Runs in the DEBUG build of the library (``_lib.load_debug()``: the product does not carry the hook).
+    Returns ``(tsdf, pixmap int32[n,R,R,R] indexed [z,y,x], status)``; pixmap values as in include/tsdf_debug.h."""
+    L = _lib.load_debug()
     dev, n, R = _check_inputs(L, depth, offsets, headers, res, layout)
     if grid is not None:
         _dev_check("grid", grid, torch.float32, dev)

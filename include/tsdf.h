@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define TSDF_ABI_VERSION 6
+#define TSDF_ABI_VERSION 7
 
 /* Output volume layouts.  Both hold float32[n][3][R][R][R]; channel c = x,y,z component. */
 enum tsdf_layout {
@@ -320,38 +320,26 @@ int tsdf_normalize_joints_hip(const float *d_gt, const float *d_max_l, const flo
 int tsdf_denormalize_joints_hip(const float *d_pred, const float *d_max_l, const float *d_mid_p, int n,
                                 int n_joints, void *hip_stream, float *d_out_joints);
 
-/*
- * Diagnostic: the voxelizer with its pixel map.  Same kernel code path as tsdf_voxelize_hip /
- * tsdf_voxelize_grid_hip (d_grid NULL / non-NULL) — projection tables, LDS-DMA staging, gather — with one
- * extra store per voxel:  d_out_pixmap int32[n][R][R][R], indexed [z][y][x] whatever the layout, holds the
- * gathered element index (pix_y - top) * b_w + pix_x - left (pre/tsdf_numba.py:38), -1 when the voxel
- * projects outside the bounding box (:36-37), -2 - index when the pixel there is invalid (:40-41).
- * Tests compare it exactly with the oracle's map.  Slower than the production entry (the staged image is the
- * whole bounding box instead of the rectangle of valid pixels, so more frames gather from global memory).
- */
-int tsdf_debug_pixmap_hip(const float *d_depth, int64_t depth_len, const int64_t *d_offsets, const int32_t *d_headers,
-                          int n, int R, const tsdf_cam *cam, int layout, void *hip_stream, const float *d_grid,
-                          float *d_out_tsdf, int32_t *d_out_pixmap, int32_t *d_out_status);
-
 /* Forget the work-queue word kept for `hip_stream` on the current device (call it when destroying a stream that
  * has no voxelizer launch in flight; optional — an unknown stream is not an error).  Returns TSDF_OK. */
 int tsdf_stream_release(void *hip_stream);
 
 /* ---- ABI v6 (adds only) ----
  * Which kernel a call would launch on the current device: writes the instantiation's name — e.g.
- * "tsdf_fused_kernel<32, 0, false, false, 2>" or "tsdf_split_kernel<32, 0, false, true> x8" — into buf (at most
+ * "tsdf_fused_kernel<32, 0, false, false, 2>" or "tsdf_split_kernel<32, 0, false, x8" (v7) — into buf (at most
  * buflen bytes, NUL-terminated) for a batch of n frames at resolution R in the given layout, plain (aug = 0) or
  * augmented (aug != 0).  Launches nothing.  bench.py names the kernel of its roofline with it.  Returns TSDF_OK,
  * TSDF_ERR_INVALID_ARG or TSDF_ERR_NO_DEVICE. */
 int tsdf_describe_launch(int n, int R, int layout, int aug, char *buf, int buflen);
 
-/* Diagnostic: overwrite the work-queue word kept for `hip_stream` on the current device with `value` (synchronous;
- * the stream must be idle).  The word's state must never matter — a launch re-initialises a word that is not in its
- * own epoch (tsdf_hip.hip: queue_ticket) — and this is how tests/test_parity_gpu.py proves it: it poisons the word the
- * way a launch that died mid-flight would have left it and checks that the next launch still voxelizes every frame
- * (the reference's loop processes every frame of a gesture, pre/read_MSRA.py:98-106).  Returns TSDF_OK, or
- * TSDF_ERR_INVALID_ARG when the stream has no word (more than 1024 live streams, stream capture). */
-int tsdf_debug_set_queue_word(void *hip_stream, uint64_t value);
+/* ---- ABI v7 ----
+ * Removes tsdf_debug_pixmap_hip and tsdf_debug_set_queue_word from the product library: test hooks do not belong in a
+ * shipping ABI (one of them synchronised a stream, against this header's own "entries never synchronise").  They are
+ * declared in include/tsdf_debug.h and exist only in the debug build of the same sources (make -C .../csrc debug ->
+ * build/libtsdf_hip_debug.so, -DTSDF_DEBUG_HOOKS), which the test-suite loads for the tests that need them.  Nothing else
+ * changed: a v6 caller that used neither hook runs unmodified.
+ * tsdf_describe_launch names a split launch by family only ("tsdf_split_kernel<32, 0, false, x8"): whether the exchange
+ * or the redundant form runs depends on the stream the launch is issued on. */
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,9 @@
 #include <string.h>
 
 #include "tsdf.h"
+#ifdef ABI_HOST_DEBUG_LIB /* linked against build/libtsdf_hip_debug.so: the hooks of include/tsdf_debug.h as well */
+#include "tsdf_debug.h"
+#endif
 
 /* oracle/tsdf_oracle.c (test infrastructure) */
 int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32_t *headers, int n, int R,
@@ -246,6 +249,7 @@ int main(void) {
     lab.n_joints = 0;
     check(tsdf_voxelize_labels_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, stream, d_t, d_l, d_m, d_s, &lab) ==
               TSDF_ERR_INVALID_ARG, "n_joints = 0 -> TSDF_ERR_INVALID_ARG");
+#ifdef ABI_HOST_DEBUG_LIB
     /* pixel-map diagnostic against the oracle's map, frame by frame, on the oracle's own grid */
     static float ref_grid[N][8], ref_ori[N][3];
     tsdf_oracle_voxelize(depth, offsets, &headers[0][0], N, R, NULL, 0, 1, NULL, NULL, NULL, NULL, NULL, &ref_grid[0][0],
@@ -263,6 +267,7 @@ int main(void) {
       pm_ok &= memcmp(ref_pm, got_pm + (size_t)i * R * R * R, sizeof(int32_t) * R * R * R) == 0;
     }
     check(pm_ok, "  pixel maps equal the oracle's exactly");
+#endif
     /* the per-thread default stream is a legal stream argument too */
     check(tsdf_voxelize_hip(d_depth, total, d_off, d_hdr, N, R, NULL, 0, hipStreamPerThread, d_t, d_l, d_m, d_s) == TSDF_OK,
           "launch on hipStreamPerThread");

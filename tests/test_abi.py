@@ -9,10 +9,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "tsdf.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "tsdf_debug.h")
 
 
-def declared_functions():
-    text = open(HEADER).read()
+def declared_functions(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tsdf_[a-z_0-9]+)\s*\(", text)))
 
@@ -24,12 +25,33 @@ def test_header_declares_expected_entry_points():
         assert must in names
 
 
+def exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("tsdf_"))
+
+
 def test_library_exports_every_declared_symbol(pkg):
     L = pkg._lib.load()
     for name in declared_functions():
         assert hasattr(L, name), f"libtsdf_hip.so does not export {name}"
-    assert L.tsdf_version() == 6
+    assert L.tsdf_version() == 7
     assert b"no CPU fallback" in L.tsdf_strerror(-2)
+    # exactly the header, nothing else: no test hook in the shipping library (ABI v7)
+    assert exported(pkg._lib.LIB_PATH) == declared_functions()
+    assert not [n for n in exported(pkg._lib.LIB_PATH) if "debug" in n]
+
+
+def test_debug_build_exports_the_product_abi_plus_the_hooks(pkg):
+    """build/libtsdf_hip_debug.so (-DTSDF_DEBUG_HOOKS): everything include/tsdf.h declares plus include/tsdf_debug.h."""
+    hooks = sorted(set(declared_functions(DEBUG_HEADER)) - set(declared_functions()))
+    assert hooks == ["tsdf_debug_pixmap_hip", "tsdf_debug_set_queue_word"]
+    L = pkg._lib.load_debug()
+    assert L.tsdf_version() == 7
+    assert exported(pkg._lib.DEBUG_LIB_PATH) == sorted(declared_functions() + hooks)
+    with pkg._lib.using_debug_library() as D:
+        assert pkg._lib.load() is D
+    assert pkg._lib.load() is not L
 
 
 def test_default_cam_matches_reference_constants(pkg):

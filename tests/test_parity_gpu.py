@@ -180,19 +180,25 @@ def test_plain_c_host_program(pkg, tmp_path):
     pkg_dir = os.path.join(root, "handposeestimation-with-3d-cnns_amd")
     ora_dir = os.path.join(root, "oracle")
     oracle.lib()  # makes sure libtsdf_oracle.so is built
-    exe = str(tmp_path / "abi_host")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "abi_host", "abi_host.c"),
-           "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(root, "include"),
-           "-L" + pkg_dir, "-ltsdf_hip", "-L" + ora_dir, "-ltsdf_oracle", "-L" + os.path.join(rocm, "lib"),
-           "-lamdhip64", "-lm", "-o", exe]
-    subprocess.run(cmd, check=True, capture_output=True, text=True)
-    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join(
-        [pkg_dir, ora_dir, os.path.join(rocm, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
-    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
-    sys.stdout.write(r.stdout)
-    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("ok  ") >= 32 and "FAIL" not in r.stdout
+    # the product library; then the debug build of the same sources (build/libtsdf_hip_debug.so), whose hooks
+    # (include/tsdf_debug.h: the pixel map) the program exercises as well when compiled with -DABI_HOST_DEBUG_LIB
+    for name, lib_dir, lib, defs, n_ok in (("abi_host", pkg_dir, "-ltsdf_hip", [], 30),
+                                           ("abi_host_debug", os.path.join(root, "build"), "-l:libtsdf_hip_debug.so",
+                                            ["-DABI_HOST_DEBUG_LIB"], 32)):
+        exe = str(tmp_path / name)
+        cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", *defs, os.path.join(root, "tests", "abi_host", "abi_host.c"),
+               "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(root, "include"),
+               "-L" + lib_dir, lib, "-L" + ora_dir, "-ltsdf_oracle", "-L" + os.path.join(rocm, "lib"),
+               "-lamdhip64", "-lm", "-o", exe]
+        subprocess.run(cmd, check=True, capture_output=True, text=True)
+        env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join(
+            [lib_dir, ora_dir, os.path.join(rocm, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
+        r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+        sys.stdout.write(r.stdout)
+        assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+        assert r.stdout.count("ok  ") >= n_ok and "FAIL" not in r.stdout
+        assert ("pixel maps equal" in r.stdout) == bool(defs)
 
 
 def test_random_geometry_sweep(pkg):
@@ -1010,9 +1016,9 @@ def test_split_kernel_exchange_under_contention(pkg, synth):
 
 
 def test_split_kernel_fallback_when_siblings_never_answer(tmp_path):
-    """TSDF_XCHG_POLLS=0 makes every workgroup of the exchange form give up waiting at once and stream the whole
-    frame itself: the path a workgroup takes when its siblings are not resident.  Same results (child process:
-    the bound is read once per process)."""
+    """TSDF_XCHG_POLLS=0 (honoured by the debug build only) makes every workgroup of the exchange form give up waiting at
+    once and stream the whole frame itself: the path a workgroup takes when its siblings are not resident.  Same results
+    (child process: the bound is read once per process)."""
     import subprocess
     import sys
 
@@ -1026,7 +1032,8 @@ synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
 d = torch.device("cuda:0")
 for kind, n, R in (("full", 1, 32), ("crop", 16, 32), ("full", 40, 32), ("crop", 5, 64)):
     depth, off, hdr = synth.synth_batch(n, kind, seed0=123)
-    out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d), torch.from_numpy(hdr).to(d), res=R)
+    with pkg._lib.using_debug_library():     # the debug build reads TSDF_XCHG_POLLS; the product reads no environment
+        out = pkg.voxelize(torch.from_numpy(depth).to(d), torch.from_numpy(off).to(d), torch.from_numpy(hdr).to(d), res=R)
     torch.cuda.synchronize()
     ref = oracle.voxelize(depth, off, hdr, R=R, n_threads=8)
     assert np.array_equal(out.max_l.cpu().numpy(), ref["max_l"]) and np.array_equal(out.mid_p.cpu().numpy(), ref["mid_p"])
@@ -1372,13 +1379,18 @@ def test_dirty_queue_word_cannot_skip_frames(pkg, synth):
     """VERDICT round 3, #6.  The fused kernels hand frames beyond the first per group out through a device word owned by
     the launch's stream.  Round 3 relied on the drawer of the last ticket putting the word back to 0: a launch that died
     mid-flight left it dirty and every later launch of the stream silently skipped frames.  Now the word carries the
-    launch's epoch and a drawer that finds another epoch re-initialises it (tsdf_hip.hip: queue_ticket), so NO state of
-    the word may cost a frame — the reference voxelizes every frame of a gesture (pre/read_MSRA.py:98-106).
+    launch's epoch and a drawer that finds another epoch re-initialises it (csrc/queue.inc: queue_ticket), so no word an
+    EARLIER launch (or anything else that cannot guess the next epoch) left behind may cost a frame — the reference
+    voxelizes every frame of a gesture (pre/read_MSRA.py:98-106).
     tsdf_debug_set_queue_word poisons the word the way a dead launch (foreign epoch, partial count) or anything else would
     have left it; every launch after that must equal the clean one bit for bit, in the two-group (32^3), one-group
     (64^3) and augmented instantiations."""
+    with pkg._lib.using_debug_library() as L:          # the hook and the launches it acts on: one library image
+        _dirty_queue_word_body(pkg, synth, L)
+
+
+def _dirty_queue_word_body(pkg, synth, L):
     d = dev()
-    L = pkg._lib.load()
     n = 700                                             # > 2 x 256 groups at 32^3 and > 256 at 64^3: tickets are drawn
     depth, off, hdr = synth.synth_batch(n, "crop", seed0=31000)
     td, to, th = (torch.from_numpy(a).to(d) for a in (depth, off, hdr))
@@ -1413,11 +1425,34 @@ def test_dirty_queue_word_cannot_skip_frames(pkg, synth):
         b = run()
         torch.cuda.synchronize()
         assert torch.equal(a.tsdf, want) and torch.equal(b.tsdf, want)
+    # The known limit: the epoch is host-predictable (1, 2, 3, ... per stream), and a word that already
+    # carries the NEXT launch's epoch with a count k > 0 is indistinguishable from that launch's own word after k draws:
+    # the launch skips its first k queue frames.  Only this hook can write such a word; the scan below poisons with a
+    # fixed future epoch before every launch until the stream's count reaches it, and records what happens then.
+    run = lambda out=None: pkg.voxelize(td, to, th, res=32, out=out)
+    clean = run()
+    torch.cuda.synchronize()
+    want = clean.tsdf.clone()
+    target, k, hit = 3000, 5, None
+    for i in range(3100):
+        assert L.tsdf_debug_set_queue_word(stream, (target << 32) | k) == 0
+        clean.tsdf.fill_(7.0)
+        got = run(clean)
+        torch.cuda.synchronize()
+        if not torch.equal(got.tsdf, want):
+            stale = (got.tsdf.flatten(1) == 7.0).all(dim=1).nonzero().flatten().tolist()
+            assert hit is None and stale == list(range(512, 512 + k)), (i, stale)   # the first k frames beyond 2 x 256 groups
+            hit = i
+            again = run(clean)                          # ... and the launch after it is whole again
+            torch.cuda.synchronize()
+            assert torch.equal(again.tsdf, want)
+            break
+    assert hit is not None
     # what the library says it launches for these batches (tsdf_describe_launch, ABI v6)
     buf = ctypes.create_string_buffer(128)
     assert L.tsdf_describe_launch(n, 32, 0, 0, buf, 128) == 0 and buf.value == b"tsdf_fused_kernel<32, 0, false, false, 2>"
     assert L.tsdf_describe_launch(n, 64, 0, 1, buf, 128) == 0 and buf.value == b"tsdf_fused_kernel<64, 0, true, false, 1>"
-    assert L.tsdf_describe_launch(16, 32, 1, 0, buf, 128) == 0 and buf.value.startswith(b"tsdf_split_kernel<32, 1, false, true> x")
+    assert L.tsdf_describe_launch(16, 32, 1, 0, buf, 128) == 0 and buf.value.startswith(b"tsdf_split_kernel<32, 1, false, x")
     assert L.tsdf_describe_launch(n, 48, 0, 0, buf, 128) == 0 and buf.value == b"tsdf_fused_kernel<0, 0, false, false, 1>"
     assert L.tsdf_describe_launch(n, 30, 0, 0, buf, 128) == -1 and L.tsdf_describe_launch(n, 32, 0, 0, None, 0) == -1
 

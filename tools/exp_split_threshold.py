@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Back-to-back launch time for mid-size batches with the split kernel forced on (TSDF_SPLIT_MAXN) or off: child
+"""(Needs a build with tools/patches/r05_removed_knobs.diff applied: the product no longer reads TSDF_SPLIT_MAXN.)
+Back-to-back launch time for mid-size batches with the split kernel forced on (TSDF_SPLIT_MAXN) or off: child
 processes, one per setting (the knob is read once per process)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

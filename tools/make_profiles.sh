@@ -11,7 +11,6 @@
 #   5. SQ counters of the same command                     -> where the waves' cycles go
 #   6. the augmented 64^3 kernel (BASELINE configs[4]): kernel trace + three SQ passes (tools/gpu_pmc_aug.sh)
 #   7. 1024 MSRA-like crops: kernel trace + FETCH/WRITE
-#   8. paired A/B of the two TSDF_FILL policies (LDS-DMA staging vs row-span capture), if libtsdf_hip_cap.so is there
 set -o pipefail
 TAG=${1:-r02}
 export TMPDIR=/tmp
@@ -35,11 +34,4 @@ echo "--- crops"
 PMC_MODE=crop rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/crop_trace -- python3 tools/exp_pmc.py > $OUT/crop_trace.log 2>&1 || tail -3 $OUT/crop_trace.log
 PMC_MODE=crop rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/crop_fetch -- python3 tools/exp_pmc.py > $OUT/crop_fetch.log 2>&1 || tail -3 $OUT/crop_fetch.log
 PMC_MODE=crop rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/crop_write -- python3 tools/exp_pmc.py > $OUT/crop_write.log 2>&1 || tail -3 $OUT/crop_write.log
-if [ -f build/libtsdf_hip_cap.so ]; then
-  echo "--- TSDF_FILL A/B"
-  for cfg in "full 1024" "full 4096" "crop 1024" "crop 4096"; do set -- $cfg
-    PROF_KIND=$1 PROF_N=$2 AB_BLOCKS=12 python3 tools/ab_precise.py libtsdf_hip.so libtsdf_hip_cap.so 2>&1 | grep -v amdgpu.ids
-  done > $OUT/ab_fill_policy.log 2>&1
-  cat $OUT/ab_fill_policy.log
-fi
 python3 tools/collect_profiles.py $OUT summarize2
