@@ -26,6 +26,7 @@ reader's flip restores the camera-frame sign.
 from __future__ import annotations
 
 import os
+import sys
 import queue
 import threading
 from typing import Iterator, List, NamedTuple, Optional, Sequence, Tuple
@@ -644,6 +645,72 @@ except ImportError:   # pragma: no cover  (a torch without the map: MSRA_Dataset
     _collate_map = None
 
 
+class _SlotGuard:
+    """Who else holds a ring slot's batch?  Two counts per tensor, compared with what they were when only the ring held
+    the slot:
+
+      * the Python reference count of the batch tuple and of each of its tensors — a consumer that keeps the tuple, one
+        tensor object, or anything that keeps those objects alive (a dlpack capsule, a closure, a frame a debugger or
+        ``sys.settrace`` hook holds on to);
+      * the use count of each tensor's STORAGE (``torch._C._storage_Use_Count``) — every other tensor object over the same
+        memory: a view (``t[:, 1]``), ``t.detach()``, ``t.data``, ``t.numpy()``, a tensor autograd saved for backward.
+        (Round 4 relied on a live view bumping its base tensor's Python reference count — a torch-internal side effect —
+        and did not see ``detach()`` / ``.data`` aliases at all: ADVICE round 4.)
+
+    Equality with the baseline means "only the ring"; ANY difference means "held" and the slot gets fresh tensors, so an
+    unexpected extra reference (a profiler, a different Python) costs an allocation, never a wrong batch.  What no count can
+    see is a consumer that dropped every reference but still has work queued on ANOTHER stream: order that stream after
+    the loader's (the usual rule for GPU tensors).  :func:`_slot_guard_works` checks the counting rules themselves once
+    per process; a torch on which they do not hold makes the ring hand out fresh tensors for every batch."""
+
+    __slots__ = ("batch", "_stor", "_cdata", "_base")
+
+    def __init__(self, batch):
+        self.batch = batch
+        self._stor = tuple(t.untyped_storage() for t in batch)   # (kept: a wrapper's _cdata is only valid while it lives)
+        self._cdata = tuple(s._cdata for s in self._stor)
+        self._base = None
+
+    def counts(self):
+        rc, uc, b, c = sys.getrefcount, _storage_use_count, self.batch, self._cdata
+        return (rc(b), rc(b[0]), rc(b[1]), rc(b[2]), rc(b[3]), uc(c[0]), uc(c[1]), uc(c[2]), uc(c[3]))
+
+    def arm(self):
+        """Call when every reference the ring itself keeps is in place and no local of the caller refers to the batch."""
+        self._base = self.counts()
+
+    def held(self) -> bool:
+        return self.counts() != self._base
+
+
+_storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
+_guard_ok: Optional[bool] = None
+
+
+def _slot_guard_works() -> bool:
+    """The counting rules _SlotGuard relies on, tried once on small CPU tensors: a kept tuple, a kept tensor, a view, a
+    ``detach()`` alias, a ``.data`` alias and a numpy alias must each read as "held", and dropping them as "free"."""
+    global _guard_ok
+    if _guard_ok is None:
+        ok = _storage_use_count is not None
+        if ok:
+            try:
+                holder = [PreBatched(tuple(torch.zeros(2, 3) for _ in range(4)))]
+                g = _SlotGuard(holder[0].batch)
+                g.arm()
+                ok = not g.held()
+                for make in (lambda b: b, lambda b: b[1], lambda b: b[0][:, 1], lambda b: b[2].detach(), lambda b: b[3].data,
+                             lambda b: b[0].numpy()):
+                    ref = make(holder[0].batch)
+                    ok = ok and g.held()
+                    del ref
+                    ok = ok and not g.held()
+            except Exception:   # pragma: no cover  (an API that moved)
+                ok = False
+        _guard_ok = bool(ok)
+    return _guard_ok
+
+
 class MSRA_Dataset(data.Dataset):
     """The reference's dataset class with its constructor and item tuple (3D_CNN/dataset.py:16-79):
 
@@ -774,21 +841,23 @@ class MSRA_Dataset(data.Dataset):
         the kernel reads over the link, with one event per ``kGroup`` index slots that tells when a group's words have been
         read (an index slot's words are rewritten ``iring`` batches later).
 
-        A slot is RECYCLED only when nothing outside this object refers to its batch any more.  Every slot owns its
-        tensors (separate allocations), so whoever keeps the batch tuple, one of its tensors, or any view of one (a view's
-        ``_base`` is the slot's tensor) shows up in a Python reference count; such a slot is given fresh tensors instead
-        (``replaced`` counts them) and the kept batch stays what it was — like the independent tensors the reference's
-        loader returns (3D_CNN/train.py:86-91 over numpy rows).  ``list(DataLoader(...))``, an evaluation loop that
-        collects outputs, a loss history: all safe.  What cannot be seen is a consumer that dropped every reference but
-        still has work queued on ANOTHER stream: order that stream after the loader's (the usual rule for GPU tensors)."""
+        A slot is RECYCLED only when nothing outside this object refers to its batch any more (:class:`_SlotGuard`: Python
+        reference counts of the tuple and its tensors, storage use counts for views and ``detach()`` / ``.data`` / numpy
+        aliases).  Every slot owns its tensors (separate allocations); a slot whose batch is still held is given fresh
+        tensors instead (``replaced`` counts them) and the kept batch stays what it was — like the independent tensors the
+        reference's loader returns (3D_CNN/train.py:86-91 over numpy rows).  ``list(DataLoader(...))``, an evaluation
+        loop that collects outputs, a loss history: all safe.  What cannot be seen is a consumer that dropped every
+        reference but still has work queued on ANOTHER stream: order that stream after the loader's (the usual rule for
+        GPU tensors).  On a torch where the counting rules do not hold (``_slot_guard_works``) every batch gets fresh
+        tensors: slower, never wrong."""
 
         kGroup = 16
 
         def __init__(self, rp: "ResidentPacks", bs: int, ring: int, device, frame=None, xf_table=None):
             import ctypes
-            import sys
             from . import _lib
-            self._ctypes, self._lib, self._rc = ctypes, _lib, sys.getrefcount
+            self._ctypes, self._lib = ctypes, _lib
+            self.always_fresh = not _slot_guard_works()
             ring = max(2, int(ring))
             self.iring = -(-max(ring, self.kGroup) // self.kGroup) * self.kGroup   # index slots: whole event groups
             self.bs, self.ring, self.count, self.replaced = bs, ring, 0, 0
@@ -808,7 +877,7 @@ class MSRA_Dataset(data.Dataset):
             self.labels = [None] * ring
             self.args = [None] * ring       # (tsdf, max_l, mid_p, status, byref(labels)) pointers of the C call
             self.results = [None] * ring    # [PreBatched((tsdf, gt, max_l, mid_p))]
-            self.base_rc = [None] * ring
+            self.guard = [None] * ring      # _SlotGuard of the slot's batch
             for k in range(ring):
                 self._fresh(k)
             self.read = [torch.cuda.Event() for _ in range(self.iring // self.kGroup)]
@@ -838,11 +907,7 @@ class MSRA_Dataset(data.Dataset):
         def _fresh(self, k: int) -> None:
             """New tensors for slot k (at start-up, and whenever its previous batch is still held by the consumer)."""
             self._alloc(k)
-            self.base_rc[k] = self._counts(k)      # (taken when _alloc's locals are gone: the ring's own references)
-
-        def _counts(self, k: int):
-            rc, b = self._rc, self.results[k][0].batch
-            return (rc(b), rc(b[0]), rc(b[1]), rc(b[2]), rc(b[3]))
+            self.guard[k].arm()      # (taken when _alloc's locals are gone: the ring's own references)
 
         def _alloc(self, k: int) -> None:
             R, bs, nc, dev = 32, self.bs, self.nc, self.device
@@ -857,10 +922,11 @@ class MSRA_Dataset(data.Dataset):
             self.args[k] = (tsdf.data_ptr(), max_l.data_ptr(), mid_p.data_ptr(), status.data_ptr(),
                             self._ctypes.byref(self.labels[k]))
             self.results[k] = [PreBatched((tsdf, gt, max_l, mid_p))]
+            self.guard[k] = _SlotGuard(self.results[k][0].batch)
 
         def held(self, k: int) -> bool:
-            """Does anything outside the ring still refer to slot k's batch (the tuple, a tensor, a view of one)?"""
-            return self._counts(k) != self.base_rc[k]
+            """Does anything outside the ring still refer to slot k's batch (the tuple, a tensor, any alias of one)?"""
+            return self.always_fresh or self.guard[k].held()
 
         def next_slot(self) -> int:
             """The output slot of the next batch, free to be overwritten."""

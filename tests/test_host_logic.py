@@ -475,14 +475,18 @@ def test_native_gather_equals_numpy_gather(pkg):
 
 
 def test_prebatched_ring_reference_count_rule(pkg):
-    """The host logic of MSRA_Dataset's pre-batched ring: a slot counts as held while the consumer keeps
-    its batch tuple, one of its tensors or a view of one, and then gets fresh tensors instead of being overwritten.  (The
-    GPU tier runs the real ring under DataLoader; here the GPU-facing parts are stubbed out.)"""
+    """The host logic of MSRA_Dataset's pre-batched ring (ADVICE rounds 3-4): a slot counts as held
+    while the consumer keeps its batch tuple, one of its tensors, a view of one, or an ALIAS of one that does not refer to
+    the tensor object at all (detach(), .data, numpy()) — and then gets fresh tensors instead of being overwritten.  The
+    rule must also hold inside a generator frame and under a sys.settrace hook (which keeps frames, hence locals, alive
+    longer: that may only make a slot look held, never free).  (The GPU tier runs the real ring under DataLoader; here
+    the GPU-facing parts are stubbed out.)"""
     import ctypes
     import sys
 
     ds = pkg.dataset
     Fast = ds.MSRA_Dataset._Fast
+    assert ds._slot_guard_works()
 
     class HostOnly(Fast):
         def __init__(self):
@@ -490,30 +494,73 @@ def test_prebatched_ring_reference_count_rule(pkg):
                 @staticmethod
                 def TsdfLabels(*a):
                     return ctypes.c_int(0)
-            self._rc, self._ctypes, self._lib = sys.getrefcount, ctypes, L
+            self._ctypes, self._lib, self.always_fresh = ctypes, L, False
             self.bs, self.nc, self.device, self.rp_gt = 4, 63, "cpu", torch.zeros(2, 63)
             self.ring, self.count, self.replaced = 2, 0, 0
-            self.slots, self.labels, self.args, self.results, self.base_rc = ([None] * 2 for _ in range(5))
+            self.slots, self.labels, self.args, self.results, self.guard = ([None] * 2 for _ in range(5))
             for k in range(2):
                 self._fresh(k)
 
-    f = HostOnly()
-    assert not f.held(0) and not f.held(1)
-    b = ds._collate_prebatched(f.results[0])          # what torch's default_collate hands the consumer
-    assert f.held(0) and not f.held(1)
-    del b
-    assert not f.held(0)
-    t = f.results[0][0].batch[0]
-    assert f.held(0)
-    v = t[:, 1]                                        # a view: its _base is the slot's tensor
-    del t
-    assert f.held(0)
-    del v
-    assert not f.held(0)
-    assert f.next_slot() == 0 and f.replaced == 0      # free slot: reused as it is
-    keep = f.results[0][0].batch[2]
-    assert f.next_slot() == 0 and f.replaced == 1      # held slot: new tensors, the kept one untouched
-    assert keep.data_ptr() != f.results[0][0].batch[2].data_ptr()
+    def scenario():
+        f = HostOnly()
+        assert not f.held(0) and not f.held(1)
+        b = ds._collate_prebatched(f.results[0])          # what torch's default_collate hands the consumer
+        assert f.held(0) and not f.held(1)
+        del b
+        assert not f.held(0)
+        t = f.results[0][0].batch[0]
+        assert f.held(0)
+        v = t[:, 1]                                        # a view: its _base is the slot's tensor
+        del t
+        assert f.held(0)
+        del v
+        assert not f.held(0)
+        # aliases that do NOT refer to the slot's tensor object: only the storage's use count sees them
+        for alias in (lambda x: x.detach(), lambda x: x.data, lambda x: x.numpy(), lambda x: x.view(-1)[3:5].detach(),
+                      lambda x: torch.as_strided(x, (2,), (1,))):
+            for which in range(4):
+                a = alias(f.results[0][0].batch[which])
+                assert f.held(0) and not f.held(1), (which, alias)
+                del a
+                assert not f.held(0)
+        assert f.next_slot() == 0 and f.replaced == 0      # free slot: reused as it is
+        keep = f.results[0][0].batch[2].detach()           # an alias, not the tensor
+        ptr = keep.data_ptr()
+        assert f.next_slot() == 0 and f.replaced == 1      # held slot: new tensors, the kept one untouched
+        assert ptr != f.results[0][0].batch[2].data_ptr() and keep.data_ptr() == ptr
+        del keep
+        # a consumer that is a generator: the batch lives in its suspended frame
+        def consumer():
+            held = ds._collate_prebatched(f.results[1])
+            yield 1
+            yield held[0].shape
+        g = consumer()
+        assert not f.held(1)
+        next(g)
+        assert f.held(1)                                   # suspended frame holds the batch
+        next(g)
+        g.close()
+        del g
+        assert not f.held(1)
+        # a torch on which the counting rules do not hold: every batch gets fresh tensors
+        f.always_fresh = True
+        assert f.held(0) and f.held(1)
+        return True
+
+    assert scenario()
+    # the same under a trace hook (debuggers, coverage tools): frames and locals are visible to it, nothing may read as free
+    # that is held
+    seen = []
+    def tracer(frame, event, arg):
+        if event == "call" and len(seen) < 4:
+            seen.append(frame)                              # keeps a few frames alive on purpose
+        return None
+    sys.settrace(tracer)
+    try:
+        assert scenario()
+    finally:
+        sys.settrace(None)
+    del seen[:]
 
 
 def test_design_quotes_the_tracked_rocprof_numbers():

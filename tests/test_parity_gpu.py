@@ -1500,7 +1500,19 @@ def test_prebatched_ring_never_overwrites_a_batch_the_consumer_holds(pkg, synth)
         for v, exp in zip(views, ref):
             assert torch.equal(v, exp[0][:, 2, 5])
         assert fast._fast.replaced > rep0
-        del kept, views
+        # (4) only ALIASES kept that do not refer to the slot's tensor objects at all: detach() of the volumes, .data of
+        # the labels (round 4's reference-count rule did not see these: ADVICE round 4) — storage use counts do
+        rep1 = fast._fast.replaced
+        al_t, al_g = [], []
+        for b in DL(fast, batch_size=bs, shuffle=True, generator=gen()):
+            al_t.append(b[0].detach())
+            al_g.append(b[1].data)
+            del b
+        torch.cuda.synchronize()
+        for t_, g_, exp in zip(al_t, al_g, ref):
+            assert torch.equal(t_, exp[0]) and torch.equal(g_, exp[1])
+        assert fast._fast.replaced > rep1 and not fast._fast.always_fresh
+        del kept, views, al_t, al_g
     # an explicit ring below 2 is raised to 2; the default is sized by bytes (2 GiB of volumes, 2..256 slots)
     assert pkg.MSRA_Dataset.from_raw(raw, device=d, ring=1)._ring_size(16) == 2
     assert pkg.MSRA_Dataset.from_raw(raw, device=d)._ring_size(16) == 256
