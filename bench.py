@@ -970,6 +970,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs / latency table (rank 0, N=1)")
     ap.add_argument("--no-config3", action="store_true", help="skip configs[3]_sharded (every rank, every N)")
+    ap.add_argument("--no-same-batch", action="store_true",
+                    help="skip the one-batch-re-launched pass behind roofline.frac_same_batch (profile runs: every traced "
+                         "launch of the kernel is then a launch of the rotation, and the trace's average is roofline's)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the three rocprofv3 PMC child passes that measure roofline.traffic (rank 0, N=1)")
     args = ap.parse_args()
@@ -1106,16 +1109,18 @@ def main():
     my_event_ms = be.elapsed_ms(ev0, ev1)
 
     # the same number of launches over ONE batch (what rounds 1-4 reported as the headline): outside the timed region
-    ev2, ev3 = be.event(), be.event()
-    for _ in range(LAUNCHES_PER_STEP):
-        be.launch(td, to, th, out)
-    be.sync()
-    be.record(ev2)
-    for _ in range(n_launch):
-        be.launch(td, to, th, out)
-    be.record(ev3)
-    be.sync()
-    same_ms = be.elapsed_ms(ev2, ev3) / n_launch
+    same_ms = float("nan")
+    if not args.no_same_batch:
+        ev2, ev3 = be.event(), be.event()
+        for _ in range(LAUNCHES_PER_STEP):
+            be.launch(td, to, th, out)
+        be.sync()
+        be.record(ev2)
+        for _ in range(n_launch):
+            be.launch(td, to, th, out)
+        be.record(ev3)
+        be.sync()
+        same_ms = be.elapsed_ms(ev2, ev3) / n_launch
 
     timing = gather([elapsed, my_event_ms, same_ms] + seeds)          # [world][3 + ROTATION]
     elapsed_max = float(timing[:, 0].max())
@@ -1214,7 +1219,8 @@ def main():
                 # every rank's own roofline fraction: its algorithmic bytes per second over the 8 TB/s of ITS GPU
                 "frac_of_hbm_peak_events": [round(abytes * n_launch / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                             for v in timing[:, 1]],
-                "frac_of_hbm_peak_same_batch": [round(abytes / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for v in timing[:, 2]],
+                "frac_of_hbm_peak_same_batch": [(round(abytes / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v == v else None)
+                                                for v in timing[:, 2]],
                 "batch_seed0": [[int(v) for v in row[3:]] for row in timing],
                 "what": "every rank's own timed region: HIP events on its launch stream, and host wall between the two barriers; "
                         "batch_seed0 = the first seed of each of the rank's resident batches (1024 consecutive seeds each)",
@@ -1226,8 +1232,8 @@ def main():
                 "what": f"the timed region itself: every launch takes the next of {ROTATION} resident batches and output buffer sets "
                         f"({working_set / 1e9:.2f} GB of distinct memory >> the 256 MiB Infinity Cache), so no launch finds its input "
                         "in a cache; frac_same_batch = the same number of launches over ONE batch (rounds 1-4's headline)",
-                "frac_same_batch": round(abytes / (same_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "launch_ms_mean_same_batch": round(float(same_ms), 4),
+                "frac_same_batch": (round(abytes / (same_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if same_ms == same_ms else None),
+                "launch_ms_mean_same_batch": (round(float(same_ms), 4) if same_ms == same_ms else None),
                 "rotation": ROTATION, "working_set_bytes": working_set,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                 "kernel": be.kernel_name(FRAMES_PER_LAUNCH, RES), "algorithmic_bytes_per_launch": abytes,

@@ -290,8 +290,10 @@ int tsdf_oracle_voxelize(const float *depth, const int64_t *offsets, const int32
  *           sign and the z component are those of the plain path bit for bit; x and y differ from it in the
  *           association of one product (<= 2 ulp of float64, i.e. nothing after the float32 store except at
  *           the exact tie of a rounding).  Round 2 formed w and T(w) explicitly (about twice the float64
- *           operations per voxel); the kernel that implements this contract is VALU-bound, which is why the
- *           contract — a re-specification this project owns — is written in its cheapest exact form.
+ *           operations per voxel), and the kernel that implemented it was bound by instruction issue — which is
+ *           why the contract, a re-specification this project owns, is written in its cheapest exact form.
+ *           (Since round 4 that kernel is bound by its volume stores first — without any per-voxel arithmetic it
+ *           would be 11 % faster, DESIGN.md (d) —, as include/tsdf.h says too.)
  */
 /* Inverse map (voxel centre back into the camera frame): every product and sum rounded separately, grouped as
  * (A_i0 x + A_i1 y) + (A_i2 z + b_i) — both brackets depend on grid indices only, so an implementation may

@@ -6,6 +6,8 @@ the same buffers, so box-to-box and minute-to-minute drift cancels and a 1 % dif
     env: PROF_KIND=full|crop  PROF_N=1024  PROF_R=32  AB_BLOCKS=30  AB_LAUNCHES=40
          AB_AUG=1: the augmented entry (tsdf_voxelize_aug_hip) with reference-distribution maps instead of the plain one;
          AB_TOL=x: the two builds may differ by x (default 0: they must agree bit for bit)
+         AB_ROTATE=k: while timed, every launch takes the next of k copies of the input (at distinct addresses) and of k
+                      output buffer sets — no launch finds its input in the Infinity Cache (bench.py's headline regime)
 """
 import ctypes, importlib, os, sys
 import numpy as np, torch
@@ -69,10 +71,20 @@ if AUG:
 
 
 timing = False
+ROT = max(1, int(os.environ.get("AB_ROTATE", "1")))
+rot_in = [td] + [td.clone() for _ in range(ROT - 1)]
+rot_out = [outs[0]] + [tuple(torch.empty_like(x) for x in outs[0]) for _ in range(ROT - 1)]   # shared by both libraries
+turn = [0]
 
 
 def launch(i):
+    global td
     t, ml, mp, st = outs[0] if (SAME and timing) else outs[1 - i if SWAP else i]
+    if timing and ROT > 1:
+        k = turn[0] % ROT
+        turn[0] += 1
+        td = rot_in[k]
+        t, ml, mp, st = rot_out[k]
     if AUG:
         rc = libs[i].tsdf_voxelize_aug_hip(td.data_ptr(), td.numel(), to.data_ptr(), th.data_ptr(), n, R, None, 0, stream,
                                            txf.data_ptr(), t.data_ptr(), ml.data_ptr(), mp.data_ptr(), st.data_ptr())

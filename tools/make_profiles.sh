@@ -16,14 +16,15 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
-# (a step is 16 launches: 6 steps + 1 warm-up + the 50 single launches of the spread pass = 162 launches per pass)
-BENCH="python3 bench.py --steps 6 --warmup 1 --no-extras --no-config3 --no-live-traffic"
+# (a step is 16 launches, each over the next of six resident batches: 6 steps + 1 warm-up + the 48 single launches of the
+# spread pass = 160 launches per pass, all of them launches of the rotation; the one-batch pass is skipped)
+BENCH="python3 bench.py --steps 6 --warmup 1 --no-extras --no-config3 --no-live-traffic --no-same-batch"
 python3 bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
 tail -1 $OUT/bench_unprofiled.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
-PMC_MODE=aabb rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_aabb -- python3 tools/exp_pmc.py > $OUT/pmc_fetch_aabb.log 2>&1 || { tail -5 $OUT/pmc_fetch_aabb.log; exit 1; }
+PMC_ROTATE=6 PMC_MODE=aabb rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_aabb -- python3 tools/exp_pmc.py > $OUT/pmc_fetch_aabb.log 2>&1 || { tail -5 $OUT/pmc_fetch_aabb.log; exit 1; }
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- $BENCH --no-cpu-baseline > $OUT/pmc_sq.log 2>&1 || { tail -5 $OUT/pmc_sq.log; }
 python3 tools/collect_profiles.py $OUT summarize
 echo "--- augmented 64^3"
