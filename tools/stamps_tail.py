@@ -3,6 +3,8 @@
 (diagnostic library: make -C handposeestimation-with-3d-cnns_amd/csrc stamps).  Run on the GPU box:
 
     PROF_FRAMES=1024 PROF_KIND=full python tools/stamps_tail.py
+    PROF_ROTATE=6: every launch takes the next of 6 copies of the input and of 6 output sets (bench.py's cache-cold regime)
+    STAMPS_LIB=build/libtsdf_hip_x.so: another stamps build (tools/devbuild.sh x WORK -DTSDF_STAMPS -DTSDF_DEV_ONLY32)
 
 Stamps are never cleared, so entries older than this launch's first start stamp are ignored.
 """
@@ -10,7 +12,7 @@ import ctypes, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("TSDF_HIP_LIB", os.path.join(ROOT, "build", "libtsdf_hip_stamps.so"))
+os.environ.setdefault("TSDF_HIP_LIB", os.environ.get("STAMPS_LIB") or os.path.join(ROOT, "build", "libtsdf_hip_stamps.so"))
 os.environ.setdefault("TSDF_ALLOW_LIB_OVERRIDE", "1")
 pkg = importlib.import_module("handposeestimation-with-3d-cnns_amd")
 synth = importlib.import_module("handposeestimation-with-3d-cnns_amd.synth")
@@ -22,12 +24,17 @@ G = int(os.environ.get("TSDF_GROUPS", "2"))
 depth, off, hdr = synth.synth_batch(N, kind, seed0=0)
 td, to, th = (torch.from_numpy(a).to(dev) for a in (depth, off, hdr))
 out = pkg.voxelize(td, to, th)
+ROT = max(1, int(os.environ.get("PROF_ROTATE", "1")))
+sets = [(td, out)] + [(td.clone(), pkg.voxelize(td, to, th)) for _ in range(ROT - 1)]
+turn = 0
 SL, FR, BL = 16, 8, 512
 L.tsdf_debug_read_stamps.restype = ctypes.c_int
 L.tsdf_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for rep in range(3):
-    for _ in range(3):
-        pkg.voxelize(td, to, th, out=out)
+    for _ in range(3 if ROT == 1 else 2 * ROT + 1):
+        d_, o_ = sets[turn % ROT]
+        turn += 1
+        pkg.voxelize(d_, to, th, out=o_)
     torch.cuda.synchronize()
     buf = np.zeros(BL * FR * SL, np.uint64)
     assert L.tsdf_debug_read_stamps(buf.ctypes.data, buf.size) == buf.size
