@@ -129,9 +129,22 @@ def test_end_to_end_frame(golden_dir, name):
 
 
 def test_c_vs_numpy_restatement_many_frames(synth):
-    """Two independent restatements agree bit for bit on 40 seeded frames (incl. pixel maps)."""
-    for s in range(40):
-        h, d = synth.synth_frame(1000 + s, "crop" if s % 2 else "full")
+    """Two independent restatements agree bit for bit on 40 seeded frames of the benchmark distributions and 20 of the
+    families outside them — near / far hands, corner bboxes, sparse, negative and mixed-sign depths, where the grid straddles
+    the camera plane and q = -F / v_z takes both signs and large magnitudes — incl. pixel maps."""
+    variants = [dict(bbox=(40, 20, 300, 230), base=150.0, rad=100.0, bulge=30.0),
+                dict(bbox=(130, 90, 190, 150), base=1500.0, rad=18.0, bulge=25.0),
+                dict(bbox=(0, 0, 110, 100), base=380.0, rad=45.0),
+                dict(bbox=(60, 40, 260, 200), base=420.0, rad=75.0, keep=0.012),
+                dict(bbox=(80, 60, 240, 200), base=450.0, rad=60.0, sign="neg"),
+                dict(bbox=(90, 50, 230, 190), base=300.0, rad=60.0, sign="halves"),
+                dict(bbox=(90, 50, 230, 190), base=250.0, rad=55.0, sign="checker"),
+                dict(bbox=(120, 80, 200, 160), base=40.0, rad=35.0, bulge=10.0, sign="halves"),
+                dict(bbox=(0, 0, 320, 240), base=120.0, rad=90.0, bulge=50.0, sign="checker"),
+                dict(bbox=(200, 120, 320, 240), base=700.0, rad=50.0, sign="halves")]
+    frames = [synth.synth_frame(1000 + s, "crop" if s % 2 else "full") for s in range(40)]
+    frames += [synth.synth_variant(300 + k, **variants[k % len(variants)]) for k in range(20)]
+    for h, d in frames:
         nv, mn, mx = oracle.aabb(d, h)
         nv2, mn2, mx2 = onp.aabb(d, h)
         assert nv == nv2
