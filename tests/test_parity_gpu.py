@@ -1663,7 +1663,8 @@ def test_fuzz_parity_short(pkg):
     """A short run of tools/fuzz_parity.py inside the suite (the fuzz was "a tool run, not a test"): 40
     rounds of random geometry / validity / NaNs / batch sizes either side of the split threshold / resolutions / layouts /
     plain, labelled, indexed and augmented entries / random camera constants against the oracle — status, max_l, mid_p and
-    labels bit for bit, volumes <= 1e-5.  The long runs (up to 1.4 M frames, 0 mismatches) stay in profiles/."""
+    labels bit for bit, volumes <= 1e-5, and (round 5) the EXACT pixel map of up to 24 frames on half of the plain
+    default-camera rounds, mixed-sign frames included.  The long runs (up to 1.4 M frames, 0 mismatches) stay in profiles/."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1671,7 +1672,7 @@ def test_fuzz_parity_short(pkg):
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert "'bad': 0" in last, last
+    assert "'bad': 0" in last and "'pixmaps'" in last, last
 
 
 @pytest.mark.parametrize("R", [48, 56, 64, 128])
