@@ -113,8 +113,8 @@ def glue(min_p, max_p, R=32):
     return grid, ori
 
 
-def voxels(depth, header, ori, voxel_len, trunc_dis, R=32, layout=0, want_pixmap=False):
-    """A.3 with explicit grid parameters -> tsdf f32[3,R,R,R] (and pixmap int32[R,R,R])."""
+def voxels(depth, header, ori, voxel_len, trunc_dis, R=32, layout=0, want_pixmap=False, cam=None):
+    """A.3 with explicit grid parameters -> tsdf f32[3,R,R,R] (and pixmap int32[R,R,R]); ``cam`` as in :func:`voxelize`."""
     depth = np.ascontiguousarray(depth, dtype=np.float32)
     header = np.ascontiguousarray(header, dtype=np.int32)
     ori = np.ascontiguousarray(ori, dtype=np.float32)
@@ -122,7 +122,7 @@ def voxels(depth, header, ori, voxel_len, trunc_dis, R=32, layout=0, want_pixmap
     pm = np.empty((R, R, R), np.int32) if want_pixmap else None
     lib().tsdf_oracle_voxels(_p(depth, ctypes.c_float), _p(header, ctypes.c_int32),
                              _p(ori, ctypes.c_float), float(np.float32(voxel_len)),
-                             float(np.float32(trunc_dis)), R, None, layout,
+                             float(np.float32(trunc_dis)), R, _cam(cam), layout,
                              _p(out, ctypes.c_float), _p(pm, ctypes.c_int32))
     return (out, pm) if want_pixmap else out
 

@@ -1664,7 +1664,7 @@ def test_fuzz_parity_short(pkg):
     rounds of random geometry / validity / NaNs / batch sizes either side of the split threshold / resolutions / layouts /
     plain, labelled, indexed and augmented entries / random camera constants against the oracle — status, max_l, mid_p and
     labels bit for bit, volumes <= 1e-5, and (round 5) the EXACT pixel map of up to 24 frames on half of the plain
-    default-camera rounds, mixed-sign frames included.  The long runs (up to 1.4 M frames, 0 mismatches) stay in profiles/."""
+    contiguous rounds (custom cameras and mixed-sign frames included).  The long runs (up to 1.4 M frames, 0 mismatches) stay in profiles/."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

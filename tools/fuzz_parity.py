@@ -3,7 +3,7 @@
 random geometry (widths 1..645, heights 1..240, bboxes anywhere, sparse..dense, blobs and scatter, negative / mixed-sign /
 sub-threshold depths, NaN sprinkles), random camera constants, both layouts, R in {16,32,40,64}, fused (n > 128) and split (n <= 128)
 kernels, the augmented entry with reference-distribution maps, labels.  Checks: status / max_l / mid_p / labels bit exact,
-volume <= 1e-5, and — on half of the plain default-camera rounds, through the debug build — the exact pixel map of up to 24 frames.      python tools/fuzz_parity.py [rounds=40] [seed=1]"""
+volume <= 1e-5, and — on half of the plain contiguous rounds, through the debug build — the exact pixel map of up to 24 frames.      python tools/fuzz_parity.py [rounds=40] [seed=1]"""
 import importlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,12 +99,12 @@ for rnd in range(rounds):
         bad += int((gn[okf].view(np.uint32) != r_nor[okf].view(np.uint32)).any(axis=1).sum())
     err = np.abs(got.tsdf.cpu().numpy() - ref["tsdf"]).reshape(n, -1).max(axis=1)
     bad += int((err > TOL).sum())
-    # Pixel maps, EXACT (default camera, plain, contiguous batches; through the debug build's tsdf_debug_pixmap_hip): the
+    # Pixel maps, EXACT (plain, contiguous batches, any camera; through the debug build's tsdf_debug_pixmap_hip): the
     # pixel every voxel gathers — or why it gathers none — against the oracle's, for up to 24 frames of the batch
     pm_checked = 0
-    if not aug and not indexed and cam is None and R <= 64 and n <= 300 and rng.random() < 0.5:
-        ex = oracle.voxelize(depth, off, hdr, R=R, n_threads=16, extras=True, want_tsdf=False)
-        _, pm, pst = pkg.voxel_pixels(td, to, th, res=R, layout=layout)
+    if not aug and not indexed and R <= 64 and n <= 300 and rng.random() < 0.5:
+        ex = oracle.voxelize(depth, off, hdr, R=R, n_threads=16, extras=True, want_tsdf=False, cam=ocam)
+        _, pm, pst = pkg.voxel_pixels(td, to, th, res=R, layout=layout, cam=cam)
         torch.cuda.synchronize()
         pm = pm.cpu().numpy()
         for i in (range(n) if n <= 24 else rng.choice(n, 24, replace=False)):
@@ -112,7 +112,7 @@ for rnd in range(rounds):
                 continue
             with np.errstate(all="ignore"):
                 _, want = oracle.voxels(depth[off[i]:off[i + 1]], hdr[i], ex["ori"][i], ex["grid"][i, 4], ex["grid"][i, 5], R=R,
-                                        want_pixmap=True)
+                                        want_pixmap=True, cam=ocam)
             bad += int(not np.array_equal(pm[i].reshape(-1), np.asarray(want).reshape(-1)))
             pm_checked += 1
         tot["pixmaps"] = tot.get("pixmaps", 0) + pm_checked
